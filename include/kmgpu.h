@@ -1,0 +1,193 @@
+/* kmgpu.h — C-ABI of libkmgpu.so: the MI355X (gfx950) implementation of km's
+ * `find_mutation` hot path.  Plain pointers and sizes only; every function
+ * returns an int status (KM_OK == 0) and never throws across the boundary.
+ *
+ * The reference (iric-soft/km, pure Python) has no FFI of its own: its seam is
+ * the duck-type of km/utils/Jellyfish.py plus the SWIG surface of the
+ * third-party Jellyfish binding beneath it.  Each entry point below names the
+ * reference interface it replaces (file:line into the reference tree).  The
+ * ctypes binding a km maintainer would add is shown in INTEGRATION.md and
+ * shipped as km_amd/lib.py.
+ *
+ * Threading: a handle is used from one host thread at a time.  Device work is
+ * issued on the caller's HIP stream where a `stream` argument exists
+ * (a hipStream_t passed as void*; NULL = the default stream).
+ *
+ * k-mer encoding (same as Jellyfish keys): A=0 C=1 G=2 T=3, two bits per base,
+ * first base in the most significant used bits of a uint64_t (k <= 32).
+ */
+#ifndef KMGPU_H
+#define KMGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define KM_OK          0
+#define KM_E_IO        1   /* cannot open / read the file                          */
+#define KM_E_FORMAT    2   /* not a Jellyfish `binary/sorted` file, bad header     */
+#define KM_E_K         3   /* k > 32 (key does not fit a uint64_t) or k < 2        */
+#define KM_E_ARG       4   /* NULL / out-of-range argument                         */
+#define KM_E_HIP       5   /* a HIP runtime call failed (see km_last_error)        */
+#define KM_E_NOMEM     6   /* host or device allocation failed                     */
+#define KM_E_STATE     7   /* call order violated (e.g. table not uploaded)        */
+#define KM_E_CAPACITY  8   /* a caller-provided output buffer is too small         */
+
+/* ---- per-target status written by the walk ------------------------------ */
+#define KM_T_OK          0
+#define KM_T_NODE_LIMIT  1  /* len(node_data) > max_node at an extension call:
+                               km/utils/MutationFinder.py:143-148 (host turns it
+                               back into the same sys.exit message)              */
+#define KM_T_REPEAT_KMER 2  /* a k-mer occurs twice in the target: ValueError of
+                               km/utils/common.py:55-59                          */
+#define KM_T_EMPTY       3  /* target shorter than k: `assert len(ref_mer)`,
+                               km/utils/Sequence.py:46                           */
+#define KM_T_BAD_BASE    4  /* a character outside ACGTacgt                      */
+#define KM_T_INTERNAL    5  /* workspace exhausted even in the large tier        */
+
+typedef struct kmjf kmjf_t;         /* one k-mer count database (host records + device table) */
+typedef struct km_batch km_batch_t; /* device workspace for a batch of targets                */
+
+typedef struct {
+  int32_t  k;            /* k-mer length (key_len / 2)                        */
+  int32_t  canonical;    /* header["canonical"]  (km/utils/Jellyfish.py:45)   */
+  uint64_t n_records;    /* records held (count > 0)                          */
+  uint64_t n_slots;      /* device table capacity in 32-byte slots (0 = not uploaded) */
+  uint64_t n_groups;     /* occupied slots                                    */
+  uint64_t table_bytes;  /* n_slots * 32                                      */
+  int32_t  device;       /* HIP device ordinal of the table, -1 if none       */
+  int32_t  reserved;
+} kmjf_info_t;
+
+/* Walk parameters = the CLI flags of km/argparser/find_mutation.py:5-39 as they
+ * reach Jellyfish(cutoff=ratio, n_cutoff=count) and
+ * MutationFinder(refpath, jf, steps, branchs, nodes)
+ * (km/tools/find_mutation.py:29,49-51). */
+typedef struct {
+  double   ratio;      /* -p/--ratio   : child kept iff count >= max(sum*ratio, count) */
+  int64_t  count;      /* -c/--count                                                   */
+  uint32_t max_stack;  /* -s/--steps                                                   */
+  uint32_t max_break;  /* -b/--branchs                                                 */
+  uint32_t max_node;   /* -n/--nodes                                                   */
+  uint32_t reserved;
+} km_params_t;
+
+typedef struct {
+  uint32_t n_targets;
+  uint32_t n_paths;        /* over all targets                                 */
+  uint64_t n_nodes;        /* over all targets, caps excluded                  */
+  uint64_t n_runs;         /* path run-length records over all paths           */
+  uint64_t logical_probes; /* reference-semantics Jellyfish.query calls        */
+  uint64_t table_fetches;  /* 32-byte table slots actually read by the walk    */
+  uint32_t n_big_tier;     /* targets that needed the large-workspace pass     */
+  uint32_t reserved;
+} km_batch_sizes_t;
+
+/* Host-side result arrays, all caller-allocated (numpy).  Any pointer may be
+ * NULL to skip that output.  Sizes come from km_batch_sizes().
+ *
+ * Node order per target (canonical order): the target's own
+ * k-mers in target order (node i == k-mer at position i), then walk-discovered
+ * k-mers in registration order.  The two capping nodes of
+ * km/utils/MutationFinder.py:97-98,122-123 are implicit: BigBang == n_nodes,
+ * BigCrunch == n_nodes + 1.
+ *
+ * A path (km/utils/Graph.py:220-240, caps stripped as in
+ * km/utils/MutationFinder.py:562) is a list of node indices, delivered
+ * run-length encoded: consecutive indices (i, i+1, ...) collapse into one
+ * (start, length) run.  Paths of one target are sorted by their index sequence. */
+typedef struct {
+  uint32_t* status;        /* [n_targets]   KM_T_*                                      */
+  uint32_t* aux;           /* [n_targets]   REPEAT_KMER: unused (host re-derives pos)   */
+  uint32_t* n_ref;         /* [n_targets]   k-mers in the target                        */
+  uint64_t* probes;        /* [n_targets]   logical probes                              */
+  uint64_t* node_off;      /* [n_targets+1] CSR offsets into node_kmer/node_count       */
+  uint64_t* node_kmer;     /* [n_nodes]     packed k-mers                               */
+  uint32_t* node_count;    /* [n_nodes]     counts (Jellyfish.query)                    */
+  uint32_t* path_off;      /* [n_targets+1] CSR offsets into the per-path arrays        */
+  uint64_t* run_off;       /* [n_paths+1]   CSR offsets into run_start/run_len          */
+  uint32_t* run_start;     /* [n_runs]                                                  */
+  uint32_t* run_len;       /* [n_runs]                                                  */
+  uint32_t* path_len;      /* [n_paths]     nodes on the path                           */
+  uint32_t* path_min_cov;  /* [n_paths]     min count along the path
+                                            (km/utils/MutationFinder.py:639,802)        */
+} km_batch_out_t;
+
+/* ---- database: replaces Jellyfish.__init__ (km/utils/Jellyfish.py:23-45) and
+ *      the binding's QueryMerFile / MerDNA.k() (km/utils/Jellyfish.py:24-25) --- */
+int kmjf_open(const char* path, kmjf_t** out);
+/* Build a database from in-memory records (synthetic workloads, tests, the
+ * receiving side of a broadcast).  keys/counts are copied. */
+int kmjf_from_records(const uint64_t* keys, const uint32_t* counts, uint64_t n,
+                      int k, int canonical, kmjf_t** out);
+/* An empty handle whose records live only on a device (multi-GPU receive side). */
+int kmjf_create(int k, int canonical, kmjf_t** out);
+int kmjf_close(kmjf_t* h);
+int kmjf_info(const kmjf_t* h, kmjf_info_t* info);
+/* Borrow the host record arrays (valid until kmjf_close). */
+int kmjf_records(const kmjf_t* h, const uint64_t** keys, const uint32_t** counts, uint64_t* n);
+
+/* Build the HBM-resident table on `device` from the host records. */
+int kmjf_upload(kmjf_t* h, int device);
+/* Build the table from record arrays that already sit in device memory
+ * (e.g. received through an RCCL broadcast).  The arrays are only read. */
+int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_keys,
+                            const uint32_t* d_counts, uint64_t n, void* stream);
+
+/* ---- lookups: replace Jellyfish.query (km/utils/Jellyfish.py:47-53; also the
+ *      loop of common.get_cov, km/utils/common.py:73-92) and
+ *      Jellyfish.get_child (km/utils/Jellyfish.py:55-72) ---------------------- */
+/* Host arrays in / out. */
+int kmjf_query_batch(kmjf_t* h, const uint64_t* kmers, uint64_t n, uint32_t* counts);
+/* mask bit c (A=0..T=3) set <=> child `kmer[1:]+c` (forward) or `c+kmer[:-1]`
+ * (forward == 0) is kept; counts4[4*i+c] = its count. */
+int kmjf_children_batch(kmjf_t* h, const uint64_t* kmers, uint64_t n, double ratio,
+                        int64_t n_cutoff, int forward, uint8_t* mask, uint32_t* counts4);
+/* Same, device arrays, asynchronous on `stream`. */
+int kmjf_query_batch_dev(kmjf_t* h, const uint64_t* d_kmers, uint64_t n, uint32_t* d_counts,
+                         void* stream);
+int kmjf_children_batch_dev(kmjf_t* h, const uint64_t* d_kmers, uint64_t n, double ratio,
+                            int64_t n_cutoff, int forward, uint8_t* d_mask,
+                            uint32_t* d_counts4, void* stream);
+
+/* ---- batched walk + path search: replaces, for many targets at once, the loop
+ *      body of km/tools/find_mutation.py:47-53:
+ *        MutationFinder.__init__ / __extend (km/utils/MutationFinder.py:87-165)
+ *        MutationFinder.graph_analysis     (km/utils/MutationFinder.py:496-572)
+ *        Graph.init_paths / all_shortest   (km/utils/Graph.py:63-240)
+ *        get_counts + min                  (km/utils/MutationFinder.py:490-494,639) */
+int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t max_targets,
+                    uint64_t max_total_bases, km_batch_t** out);
+int km_batch_destroy(km_batch_t* b);
+/* Targets as concatenated ASCII bases (ACGT, either case); offsets[n+1]. Copies H2D. */
+int km_batch_set_targets(km_batch_t* b, const uint8_t* bases, const uint64_t* offsets,
+                         uint32_t n_targets);
+/* Same with device-resident arrays (copied device-to-device, async on stream). */
+int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64_t* offsets_host,
+                             uint32_t n_targets, void* stream);
+#define KM_STAGE_WALK  1
+#define KM_STAGE_GRAPH 2
+/* Launch the kernels asynchronously on `stream` (no host synchronisation unless
+ * a target overflows the fast tier, in which case the large-tier pass needs one). */
+int km_batch_run(km_batch_t* b, int stages, void* stream);
+int km_batch_sync(km_batch_t* b);
+int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* sizes);
+int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
+/* Average duration (ms) of the last run's kernels measured with HIP events on the
+ * launch stream: [0] walk, [1] graph, [2] whole run. */
+int km_batch_timings(km_batch_t* b, float* ms3);
+
+/* ---- misc ---------------------------------------------------------------- */
+const char* km_strerror(int code);
+const char* km_last_error(void);   /* thread-local detail of the last failure */
+int km_device_count(int* n);
+const char* km_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMGPU_H */

@@ -1,0 +1,408 @@
+// walk_kernel.h — MutationFinder.__init__ / __extend for a batch of targets.
+//
+// Reference: km/utils/MutationFinder.py:100-124 (register the target's k-mers,
+// extend from each) and :137-165 (recursive DFS with budgets), calling
+// Jellyfish.get_child / query (km/utils/Jellyfish.py:47-72).
+//
+// One 64-lane workgroup (= one wavefront) per target.
+//
+//  Phase A (lane-parallel, the bulk of all probes).  Lane j handles target
+//  k-mers j, j+64, ...: it inserts the k-mer into the per-target node set (LDS,
+//  open addressing; a duplicate raises the reference's ValueError), fetches ONE
+//  32-byte sibling bucket from HBM (device_common.h) which yields the four child
+//  counts of get_child AND the count of the next target k-mer, thresholds the
+//  children and classifies the seed: "trivial" when it has no child or its only
+//  child is the next target k-mer (then __extend registers nothing new), else it
+//  is flagged in an LDS bitmap.  Trivial seeds cannot change node_data, so
+//  handling them out of order is exact.
+//
+//  Phase B (wave-uniform).  Flagged seeds are walked one after the other in
+//  target order with the reference's exact DFS semantics (child order ACGT,
+//  len(stack) > max_stack, breaks > max_break, node limit checked at every
+//  extension call, registration of the whole stack on a rejoin or a loop).  All
+//  64 lanes cooperate on each step: set membership is one LDS window read +
+//  ballot, stack registration and un-marking are lane-strided.  Only frames that
+//  still have untried children are kept as "branch frames" (at most max_break of
+//  them), so unwinding jumps straight to the next untried child.
+//
+// Node order written out (canonical order): target k-mers in target
+// order, then registered k-mers in registration (stack) order.
+//
+// The same code is instantiated twice: BIG=false keeps all per-target state in
+// LDS (fast tier); BIG=true keeps it in a global workspace and is used for the
+// few targets whose node set / stack outgrow the LDS budget.
+#pragma once
+#include "device_common.h"
+
+namespace kmd {
+
+constexpr uint32_t ST_NODE = 1, ST_ONSTACK = 2, ST_POPPED = 3;
+constexpr uint32_t T_OK = 0, T_NODE_LIMIT = 1, T_REPEAT = 2, T_EMPTY = 3, T_BAD_BASE = 4,
+                   T_INTERNAL = 5, T_NEEDS_BIG = 100;
+constexpr uint64_t DFS_STEP_LIMIT = 1ull << 32;
+
+struct __attribute__((aligned(16))) BranchFrame {
+  uint4 c4;
+  uint32_t depth, mask, brk, pad;
+};
+
+struct WalkArgs {
+  TableView tab;
+  const uint8_t* bases;
+  const uint64_t* toff;
+  const uint32_t* tids;       // BIG: target ids to (re)run; nullptr = blockIdx.x
+  uint32_t n_targets;
+  double ratio;
+  int64_t n_cutoff;
+  uint32_t max_stack, max_break, max_node;
+  // per-target outputs
+  uint64_t* node_kmer;
+  uint32_t* node_cnt;
+  const uint64_t* node_base;
+  const uint32_t* node_cap;
+  uint32_t* n_nodes;
+  uint32_t* n_ref;
+  uint32_t* status;
+  uint64_t* probes;
+  uint64_t* fetches;
+  // workspace geometry (LDS for the fast tier, per-block global for BIG)
+  uint32_t hs_cap;      // node-set slots, multiple of 64
+  uint32_t words_cap;   // packed-target words (even)
+  uint32_t fcap;        // stack frames (even) >= max_stack + 2
+  uint32_t bcap;        // branch frames >= max_break + 1
+  uint32_t flag_words;  // bitmap words
+  unsigned char* g_ws;  // BIG only
+  uint64_t g_stride;    // BIG only: bytes per block
+};
+
+__host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t words_cap,
+                                                  uint32_t fcap, uint32_t bcap,
+                                                  uint32_t flag_words) {
+  uint64_t b = 0;
+  b += (uint64_t)hs_cap * 8;       // keys
+  b += (uint64_t)words_cap * 8;    // packed target
+  b += (uint64_t)fcap * 8;         // frame k-mers
+  b += (uint64_t)bcap * 32;        // branch frames
+  b += (uint64_t)fcap * 4;         // frame counts
+  b += (uint64_t)fcap * 4;         // frame set slots
+  b += (uint64_t)((flag_words + 1) & ~1u) * 4;   // flagged-seed bitmap (kept 8-byte aligned)
+  b += 16;                         // accumulators
+  b += (uint64_t)hs_cap;           // slot states
+  return (b + 15) & ~15ull;
+}
+
+__device__ inline uint32_t set_home(uint64_t key, uint32_t cap) {
+  return (uint32_t)(((mix64(key) >> 32) * (uint64_t)cap) >> 32);
+}
+
+// Per-lane insert (distinct lanes may insert concurrently).  Returns the slot;
+// *was_new tells whether this call created the entry.
+__device__ inline int set_insert_lane(uint64_t* keys, uint32_t cap, uint64_t key, bool* was_new) {
+  uint32_t s = set_home(key, cap);
+  for (uint32_t step = 0; step < cap; ++step) {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]),
+                                       (unsigned long long)EMPTY, (unsigned long long)key);
+    if (old == EMPTY) { *was_new = true; return (int)s; }
+    if (old == key) { *was_new = false; return (int)s; }
+    if (++s == cap) s = 0;
+  }
+  *was_new = false;
+  return -1;
+}
+
+// Wave-cooperative lookup (all 64 lanes call with the same key).  Returns the
+// slot of the key (*found) or the empty slot where it would be inserted.
+__device__ inline int set_find(const uint64_t* keys, uint32_t cap, uint64_t key, bool* found) {
+  const uint32_t lane = (uint32_t)lane_id();
+  uint32_t base = set_home(key, cap);
+  for (uint32_t scanned = 0; scanned < cap + 64; scanned += 64) {
+    uint32_t s = base + lane;
+    if (s >= cap) s -= cap;
+    const uint64_t kv = keys[s];
+    const unsigned long long mm = __ballot(kv == key);
+    const unsigned long long me = __ballot(kv == EMPTY);
+    if (mm | me) {
+      const int lm = mm ? (__ffsll((long long)mm) - 1) : 64;
+      const int le = me ? (__ffsll((long long)me) - 1) : 64;
+      uint32_t pos = base + (uint32_t)(lm < le ? lm : le);
+      if (pos >= cap) pos -= cap;
+      *found = lm < le;
+      return (int)pos;
+    }
+    base += 64;
+    if (base >= cap) base -= cap;
+  }
+  *found = false;
+  return -1;
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(64) void k_walk(WalkArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t t = a.tids ? a.tids[blockIdx.x] : blockIdx.x;
+  const TableView tab = a.tab;
+  const int k = tab.k;
+
+  unsigned char* wsb;
+  if constexpr (BIG) wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
+  else wsb = smem;
+  const uint32_t cap = a.hs_cap;
+  uint64_t* keys = reinterpret_cast<uint64_t*>(wsb);
+  uint64_t* words = keys + cap;
+  uint64_t* fk = words + a.words_cap;
+  BranchFrame* bf = reinterpret_cast<BranchFrame*>(fk + a.fcap);
+  uint32_t* fc = reinterpret_cast<uint32_t*>(bf + a.bcap);
+  uint32_t* fs = fc + a.fcap;
+  uint32_t* flag = fs + a.fcap;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(flag + a.flag_words + (a.flag_words & 1));
+  uint8_t* state = reinterpret_cast<uint8_t*>(acc + 2);
+
+  const uint64_t off = a.toff[t];
+  const uint64_t L = a.toff[t + 1] - off;
+  const uint32_t n_ref = (L >= (uint64_t)k) ? (uint32_t)(L - k + 1) : 0;
+  const uint64_t nb = a.node_base[t];
+  const uint32_t node_cap = a.node_cap[t];
+
+  if (n_ref == 0) {
+    if (lane == 0) {
+      a.status[t] = T_EMPTY; a.n_nodes[t] = 0; a.n_ref[t] = 0; a.probes[t] = 0; a.fetches[t] = 0;
+    }
+    return;
+  }
+  const uint32_t nwords = (uint32_t)((L + 31) >> 5);
+  const uint32_t nflag = (n_ref + 31) >> 5;
+  if (nwords + 1 > a.words_cap || nflag > a.flag_words || n_ref > node_cap ||
+      (uint64_t)n_ref * 4 > (uint64_t)cap * 3) {
+    if (lane == 0) {
+      a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.n_nodes[t] = 0; a.n_ref[t] = n_ref;
+      a.probes[t] = 0; a.fetches[t] = 0;
+    }
+    return;
+  }
+
+  // ---- init per-target state -------------------------------------------------
+  for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
+  for (uint32_t w = lane; w < a.flag_words; w += 64) flag[w] = 0;
+  if (lane < 2) acc[lane] = 0;
+  // pack the target two bits per base, 32 bases per word, first base most significant
+  uint32_t bad = 0;
+  for (uint32_t w = lane; w <= nwords; w += 64) {
+    uint64_t v = 0;
+    if (w < nwords) {
+      const uint64_t p0 = (uint64_t)w << 5;
+      for (uint32_t j = 0; j < 32; ++j) {
+        uint32_t code = 0;
+        if (p0 + j < L) {
+          const uint32_t ch = a.bases[off + p0 + j] & 0xDFu;   // upper-case
+          bad |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
+          code = ((ch >> 1) ^ (ch >> 2)) & 3u;
+        }
+        v = (v << 2) | code;
+      }
+    }
+    words[w] = v;
+  }
+  __syncthreads();
+  if (__any((int)bad)) {
+    if (lane == 0) {
+      a.status[t] = T_BAD_BASE; a.n_nodes[t] = 0; a.n_ref[t] = n_ref; a.probes[t] = 0; a.fetches[t] = 0;
+    }
+    return;
+  }
+  auto kmer_at = [&](uint32_t i) -> uint64_t {
+    const uint32_t w = i >> 5, sh = (i & 31) * 2;
+    const uint64_t hi = words[w], lo = words[w + 1];
+    const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+    return x >> (64 - 2 * k);
+  };
+
+  // ---- phase A: register + one get_child per target k-mer --------------------
+  const bool no_extend = (a.max_stack == 0);   // every __extend returns at len(stack) > 0
+  uint64_t probes_l = 0;     // per-lane partial sums
+  uint32_t fetch_l = 0;
+  uint32_t dup = 0;
+  for (uint32_t base = 0; base < n_ref; base += 64) {
+    const uint32_t i = base + lane;
+    if (i < n_ref) {
+      const uint64_t X = kmer_at(i);
+      bool was_new;
+      const int s = set_insert_lane(keys, cap, X, &was_new);
+      if (s >= 0 && was_new) state[s] = (uint8_t)ST_NODE;
+      if (s < 0 || !was_new) dup = 1;
+      a.node_kmer[nb + i] = X;
+      const uint4 c4 = forward_children(tab, X, &fetch_l);
+      uint32_t nextb = 4;
+      if (i + 1 < n_ref) {
+        nextb = (uint32_t)(kmer_at(i + 1) & 3);
+        a.node_cnt[nb + i + 1] = pick4(c4, nextb);
+      }
+      if (i == 0) a.node_cnt[nb] = query_one(tab, X, &fetch_l);
+      probes_l += 1;                                    // node_data[s] = jf.query(s)
+      if (!no_extend) {
+        const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
+        const bool trivial = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
+        if (trivial) {
+          probes_l += 4 + (mask ? 1 : 0);               // get_child + re-query of [seed]
+        } else {
+          atomicOr(&flag[i >> 5], 1u << (i & 31));
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  uint32_t st = T_OK;
+  uint32_t n_nodes = n_ref;
+  uint64_t probes_u = 0;     // wave-uniform part (phase B)
+  uint32_t fetch_u = 0;
+  if (__any((int)dup)) st = T_REPEAT;
+  else if (!no_extend && n_nodes > a.max_node) st = T_NODE_LIMIT;
+
+  // ---- phase B: exact DFS from every flagged seed, in target order ------------
+  if (st == T_OK && !no_extend) {
+    uint32_t set_count = n_ref;
+    const uint32_t set_limit = (uint32_t)(((uint64_t)cap * 3) >> 2);
+    uint64_t steps = 0;
+    for (uint32_t w = 0; w < nflag && st == T_OK; ++w) {
+      uint32_t bits = flag[w];
+      while (bits && st == T_OK) {
+        const uint32_t b = (uint32_t)__ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const uint32_t i = w * 32 + b;
+        uint64_t cur = kmer_at(i);
+        bool fnd;
+        const int sslot = set_find(keys, cap, cur, &fnd);
+        if (lane == 0) { fk[0] = cur; fc[0] = 0; fs[0] = (uint32_t)sslot; }
+        uint32_t depth = 1, reg = 1, bsp = 0, parent_brk = 0, mask = 0, brk = 0;
+        uint4 c4 = make_uint4(0, 0, 0, 0);
+        bool need_expand = true;
+        __syncthreads();
+        while (true) {
+          if (++steps > DFS_STEP_LIMIT) { st = T_INTERNAL; break; }
+          if (need_expand) {
+            need_expand = false;
+            if (n_nodes > a.max_node) { st = T_NODE_LIMIT; break; }
+            c4 = forward_children(tab, cur, &fetch_u);
+            probes_u += 4;
+            mask = child_mask(c4, a.ratio, a.n_cutoff);
+            brk = parent_brk;
+            if (__popc(mask) > 1) {
+              ++brk;
+              if (brk > a.max_break) mask = 0;
+            }
+          }
+          if (mask == 0) {
+            if (bsp == 0) break;                         // DFS from this seed is done
+            --bsp;
+            const BranchFrame f = bf[bsp];
+            for (uint32_t j = f.depth + lane; j < depth; j += 64) {
+              const uint32_t s = fs[j];
+              if (state[s] == ST_ONSTACK) state[s] = (uint8_t)ST_POPPED;
+            }
+            depth = f.depth;
+            if (reg > depth) reg = depth;
+            cur = fk[depth - 1];
+            c4 = f.c4; mask = f.mask; brk = f.brk;
+            __syncthreads();
+            continue;
+          }
+          const uint32_t c = (uint32_t)__ffs((int)mask) - 1;
+          mask &= mask - 1;
+          const uint64_t child = ((cur << 2) | c) & tab.kmask;
+          const uint32_t ccnt = pick4(c4, c);
+          bool found;
+          int slot = set_find(keys, cap, child, &found);
+          if (slot < 0) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
+          const uint32_t stt = found ? (uint32_t)state[slot] : 0u;
+          if (found && (stt == ST_NODE || stt == ST_ONSTACK)) {
+            // rejoin (or loop): for p in stack: node_data[p] = jf.query(p)
+            probes_u += depth;
+            if (reg < depth) {
+              const uint32_t add = depth - reg;
+              if (n_nodes + add > node_cap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
+              for (uint32_t j = reg + lane; j < depth; j += 64) {
+                a.node_kmer[nb + n_nodes + (j - reg)] = fk[j];
+                a.node_cnt[nb + n_nodes + (j - reg)] = fc[j];
+                state[fs[j]] = (uint8_t)ST_NODE;
+              }
+              n_nodes += add;
+              reg = depth;
+              __syncthreads();
+            }
+          } else if (depth + 1 <= a.max_stack) {
+            // __extend(stack + [child], breaks)
+            if (!found && set_count + 1 > set_limit) {
+              // drop the POPPED tombstones: rebuild the set from nodes + live stack
+              __syncthreads();
+              for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
+              __syncthreads();
+              bool wn;
+              for (uint32_t j = lane; j < n_nodes; j += 64) {
+                const int s2 = set_insert_lane(keys, cap, a.node_kmer[nb + j], &wn);
+                if (s2 >= 0) state[s2] = (uint8_t)ST_NODE;
+              }
+              __syncthreads();
+              for (uint32_t j = lane; j < depth; j += 64) {
+                const int s2 = set_insert_lane(keys, cap, fk[j], &wn);
+                if (s2 >= 0) {
+                  if (wn) state[s2] = (uint8_t)ST_ONSTACK;
+                  fs[j] = (uint32_t)s2;
+                }
+              }
+              __syncthreads();
+              set_count = n_nodes + (depth - reg);
+              if (set_count + 1 > set_limit) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
+              slot = set_find(keys, cap, child, &found);
+              if (slot < 0 || found) { st = T_INTERNAL; break; }
+            }
+            if (mask != 0) {
+              if (bsp >= a.bcap) { st = T_INTERNAL; break; }
+              if (lane == 0) {
+                BranchFrame f;
+                f.c4 = c4; f.depth = depth; f.mask = mask; f.brk = brk; f.pad = 0;
+                bf[bsp] = f;
+              }
+              ++bsp;
+            }
+            if (!found) ++set_count;
+            if (lane == 0) {
+              if (!found) keys[slot] = child;
+              state[slot] = (uint8_t)ST_ONSTACK;
+              fk[depth] = child; fc[depth] = ccnt; fs[depth] = (uint32_t)slot;
+            }
+            parent_brk = brk;
+            ++depth;
+            cur = child;
+            need_expand = true;
+            __syncthreads();
+          }
+          // else: the child's __extend returns at once (len(stack) > max_stack)
+        }
+        if (st != T_OK) break;
+        for (uint32_t j = 1 + lane; j < depth; j += 64) {
+          const uint32_t s = fs[j];
+          if (state[s] == ST_ONSTACK) state[s] = (uint8_t)ST_POPPED;
+        }
+        __syncthreads();
+        // the next seed's __extend call (there is one unless this was the last
+        // target k-mer) checks the node limit first
+        if (n_nodes > a.max_node && i + 1 < n_ref) st = T_NODE_LIMIT;
+      }
+    }
+  }
+
+  // ---- results -----------------------------------------------------------------
+  atomicAdd(&acc[0], (unsigned long long)probes_l);
+  atomicAdd(&acc[1], (unsigned long long)fetch_l);
+  __syncthreads();
+  if (lane == 0) {
+    a.status[t] = st;
+    a.n_nodes[t] = n_nodes;
+    a.n_ref[t] = n_ref;
+    a.probes[t] = (uint64_t)acc[0] + probes_u;
+    a.fetches[t] = (uint64_t)acc[1] + fetch_u;
+  }
+}
+
+}  // namespace kmd

@@ -1,0 +1,89 @@
+"""Batched counterpart of the reference's per-target loop.
+
+km/tools/find_mutation.py:47-58 builds one ``MutationFinder`` per target and
+runs ``graph_analysis`` on it, target after target.  :class:`BatchFinder` hands
+ALL targets of a run to the GPU in one ``km_batch_run`` (walk + path search) and
+then rebuilds, per target, the objects the host-side reporting needs.
+"""
+
+import numpy as np
+
+from . import lib as _lib
+from . import report
+
+
+class NodeLimitExceeded(Exception):
+    """MutationFinder.py:143-148 — the reference calls sys.exit with this text."""
+
+    def __init__(self, max_node):
+        self.max_node = max_node
+        super().__init__("ERROR: Node query count limit exceeded: max=%d" % max_node)
+
+
+def repeated_kmer_message(seq, name, k):
+    """The ValueError text of km/utils/common.py:55-59 for the first repeated k-mer."""
+    seen = set()
+    for pos in range(len(seq) - k + 1):
+        mer = seq[pos:pos + k]
+        if mer in seen:
+            return "%s found multiple times in reference %s, at pos. %d" % (mer, name, pos)
+        seen.add(mer)
+    return None
+
+
+class BatchFinder:
+    def __init__(self, jf, max_stack=500, max_break=10, max_node=10000):
+        self.jf = jf
+        self.max_stack, self.max_break, self.max_node = max_stack, max_break, max_node
+        self._batch = None
+        self._cap = (0, 0)
+
+    def _ensure(self, n_targets, n_bases):
+        if self._batch is None or n_targets > self._cap[0] or n_bases > self._cap[1]:
+            if self._batch is not None:
+                self._batch.close()
+            cap = (max(n_targets, 64), max(n_bases, 1 << 16))
+            self._batch = _lib.Batch(self.jf.db, self.jf.cutoff, self.jf.n_cutoff, self.max_stack,
+                                     self.max_break, self.max_node, cap[0], cap[1])
+            self._cap = cap
+        return self._batch
+
+    def run_raw(self, seqs, stream=None):
+        """Walk + path search for a list of sequences; returns the raw result dict."""
+        b = self._ensure(len(seqs), sum(len(s) for s in seqs))
+        b.set_targets(seqs)
+        b.run(stream=stream)
+        return b.fetch()
+
+    def analyse(self, targets):
+        """targets: list of (name, seq).  Returns a list with one TargetResult per
+        target, or the exception the reference would have raised at that target."""
+        names = [t[0] for t in targets]
+        seqs = [t[1] for t in targets]
+        k = self.jf.k
+        raw = self.run_raw(seqs)
+        # RefSeq construction comes first for every target in the reference
+        # (km/tools/find_mutation.py:37-45): its errors pre-empt all output
+        for t, st in enumerate(raw["status"].tolist()):
+            if st == _lib.T_EMPTY:
+                raise AssertionError("target %s is shorter than k=%d" % (names[t], k))
+            if st == _lib.T_BAD_BASE:
+                raise ValueError("target %s contains characters other than ACGT" % names[t])
+            if st == _lib.T_REPEAT_KMER:
+                raise ValueError(repeated_kmer_message(seqs[t], names[t], k))
+            if st == _lib.T_INTERNAL:
+                raise RuntimeError("libkmgpu: internal workspace overflow on target %s" % names[t])
+        out = []
+        noff = raw["node_off"]
+        poff = raw["path_off"]
+        for t in range(len(targets)):
+            if raw["status"][t] == _lib.T_NODE_LIMIT:
+                out.append(NodeLimitExceeded(self.max_node))
+                continue
+            a, e = int(noff[t]), int(noff[t + 1])
+            paths = [_lib.expand_path(raw, p) for p in range(int(poff[t]), int(poff[t + 1]))]
+            mc = raw["path_min_cov"][int(poff[t]):int(poff[t + 1])].tolist()
+            out.append(report.TargetResult(names[t], seqs[t], k, int(raw["n_ref"][t]),
+                                           raw["node_kmer"][a:e], raw["node_count"][a:e], paths, mc,
+                                           int(raw["probes"][t])))
+        return out

@@ -1,0 +1,333 @@
+"""ctypes binding of libkmgpu.so (include/kmgpu.h).
+
+This is the whole Python<->native boundary: plain pointers and sizes, numpy
+arrays own every in/out buffer.  There is NO CPU fallback — if the HIP library
+is missing or cannot be loaded, :func:`load` raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkmgpu.so")
+
+KM_OK = 0
+KM_STAGE_WALK, KM_STAGE_GRAPH = 1, 2
+T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
+
+# every symbol include/kmgpu.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "kmjf_open", "kmjf_from_records", "kmjf_create", "kmjf_close", "kmjf_info", "kmjf_records",
+    "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
+    "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
+    "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_strerror", "km_last_error",
+    "km_device_count", "km_version",
+]
+
+
+class KmError(RuntimeError):
+    def __init__(self, code, detail):
+        self.code = code
+        super().__init__("libkmgpu: %s" % detail)
+
+
+class JfInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("canonical", C.c_int32), ("n_records", C.c_uint64),
+                ("n_slots", C.c_uint64), ("n_groups", C.c_uint64), ("table_bytes", C.c_uint64),
+                ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("ratio", C.c_double), ("count", C.c_int64), ("max_stack", C.c_uint32),
+                ("max_break", C.c_uint32), ("max_node", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BatchSizes(C.Structure):
+    _fields_ = [("n_targets", C.c_uint32), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint64),
+                ("n_runs", C.c_uint64), ("logical_probes", C.c_uint64),
+                ("table_fetches", C.c_uint64), ("n_big_tier", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_P32 = C.POINTER(C.c_uint32)
+_P64 = C.POINTER(C.c_uint64)
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("status", _P32), ("aux", _P32), ("n_ref", _P32), ("probes", _P64),
+                ("node_off", _P64), ("node_kmer", _P64), ("node_count", _P32),
+                ("path_off", _P32), ("run_off", _P64), ("run_start", _P32), ("run_len", _P32),
+                ("path_len", _P32), ("path_min_cov", _P32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libkmgpu.so (built in-tree by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("km_amd: %s is missing — run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, cp = C.c_void_p, C.c_char_p
+    u32, u64, i32, i64, dbl = C.c_uint32, C.c_uint64, C.c_int, C.c_int64, C.c_double
+    sig = {
+        "kmjf_open": [cp, C.POINTER(vp)],
+        "kmjf_from_records": [vp, vp, u64, i32, i32, C.POINTER(vp)],
+        "kmjf_create": [i32, i32, C.POINTER(vp)],
+        "kmjf_close": [vp],
+        "kmjf_info": [vp, C.POINTER(JfInfo)],
+        "kmjf_records": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
+        "kmjf_upload": [vp, i32],
+        "kmjf_upload_from_device": [vp, i32, vp, vp, u64, vp],
+        "kmjf_query_batch": [vp, vp, u64, vp],
+        "kmjf_children_batch": [vp, vp, u64, dbl, i64, i32, vp, vp],
+        "kmjf_query_batch_dev": [vp, vp, u64, vp, vp],
+        "kmjf_children_batch_dev": [vp, vp, u64, dbl, i64, i32, vp, vp, vp],
+        "km_batch_create": [vp, C.POINTER(Params), u32, u64, C.POINTER(vp)],
+        "km_batch_destroy": [vp],
+        "km_batch_set_targets": [vp, vp, vp, u32],
+        "km_batch_set_targets_dev": [vp, vp, vp, u32, vp],
+        "km_batch_run": [vp, i32, vp],
+        "km_batch_sync": [vp],
+        "km_batch_sizes": [vp, C.POINTER(BatchSizes)],
+        "km_batch_fetch": [vp, C.POINTER(BatchOut)],
+        "km_batch_timings": [vp, C.POINTER(C.c_float)],
+        "km_device_count": [C.POINTER(i32)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    for name in ("km_strerror", "km_last_error", "km_version"):
+        getattr(lib, name).restype = cp
+    lib.km_strerror.argtypes = [i32]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != KM_OK:
+        lib = load()
+        detail = lib.km_last_error().decode() or lib.km_strerror(rc).decode()
+        raise KmError(rc, detail)
+
+
+def ptr(arr):
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    if arr is None:
+        return None
+    assert arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def typed_ptr(arr, ctype):
+    return None if arr is None else arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class Database:
+    """One k-mer count database: host records + HBM-resident table.
+
+    Replaces the ``QueryMerFile`` handle of km/utils/Jellyfish.py:24."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = load()
+
+    @classmethod
+    def open(cls, path):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.kmjf_open(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_records(cls, keys, counts, k, canonical=True):
+        lib = load()
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        assert keys.shape == counts.shape
+        h = C.c_void_p()
+        check(lib.kmjf_from_records(ptr(keys), ptr(counts), keys.size, int(k), int(bool(canonical)),
+                                    C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def empty(cls, k, canonical=True):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.kmjf_create(int(k), int(bool(canonical)), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.kmjf_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self):
+        inf = JfInfo()
+        check(self._lib.kmjf_info(self._h, C.byref(inf)))
+        return inf
+
+    def records(self):
+        """(keys, counts) copies of the host records."""
+        kp, cp_, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        check(self._lib.kmjf_records(self._h, C.byref(kp), C.byref(cp_), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+        keys = np.ctypeslib.as_array(C.cast(kp, _P64), shape=(n.value,)).copy()
+        counts = np.ctypeslib.as_array(C.cast(cp_, _P32), shape=(n.value,)).copy()
+        return keys, counts
+
+    def upload(self, device=0):
+        check(self._lib.kmjf_upload(self._h, int(device)))
+        return self
+
+    def upload_from_device(self, device, d_keys_ptr, d_counts_ptr, n, stream=None):
+        check(self._lib.kmjf_upload_from_device(self._h, int(device), C.c_void_p(d_keys_ptr),
+                                                C.c_void_p(d_counts_ptr), int(n),
+                                                C.c_void_p(stream or 0)))
+        return self
+
+    def query(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(kmers.size, dtype=np.uint32)
+        check(self._lib.kmjf_query_batch(self._h, ptr(kmers), kmers.size, ptr(out)))
+        return out
+
+    def children(self, kmers, ratio, n_cutoff, forward=True):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        mask = np.zeros(kmers.size, dtype=np.uint8)
+        counts4 = np.zeros((kmers.size, 4), dtype=np.uint32)
+        check(self._lib.kmjf_children_batch(self._h, ptr(kmers), kmers.size, float(ratio),
+                                            int(n_cutoff), int(bool(forward)), ptr(mask),
+                                            ptr(counts4)))
+        return mask, counts4
+
+
+class Batch:
+    """Device workspace that walks + path-searches many targets per launch."""
+
+    def __init__(self, db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
+                 max_targets=1024, max_total_bases=1 << 20):
+        self._lib = load()
+        self.db = db
+        self.params = Params(float(ratio), int(count), int(max_stack), int(max_break),
+                             int(max_node), 0)
+        self._b = C.c_void_p()
+        check(self._lib.km_batch_create(db._h, C.byref(self.params), int(max_targets),
+                                        int(max_total_bases), C.byref(self._b)))
+        self.n_targets = 0
+
+    def close(self):
+        if self._b is not None and self._b.value:
+            self._lib.km_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_targets(self, seqs):
+        """seqs: list of str/bytes (ACGT)."""
+        enc = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
+        offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+        np.cumsum([len(e) for e in enc], out=offs[1:])
+        blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+        self.set_targets_packed(blob, offs)
+
+    def set_targets_packed(self, blob, offsets):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        check(self._lib.km_batch_set_targets(self._b, ptr(blob), ptr(offsets), offsets.size - 1))
+        self.n_targets = offsets.size - 1
+
+    def set_targets_dev(self, d_bases_ptr, offsets, stream=None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        check(self._lib.km_batch_set_targets_dev(self._b, C.c_void_p(d_bases_ptr), ptr(offsets),
+                                                 offsets.size - 1, C.c_void_p(stream or 0)))
+        self.n_targets = offsets.size - 1
+
+    def run(self, stages=KM_STAGE_WALK | KM_STAGE_GRAPH, stream=None):
+        check(self._lib.km_batch_run(self._b, int(stages), C.c_void_p(stream or 0)))
+
+    def sync(self):
+        check(self._lib.km_batch_sync(self._b))
+
+    def timings(self):
+        ms = (C.c_float * 3)()
+        check(self._lib.km_batch_timings(self._b, ms))
+        return float(ms[0]), float(ms[1]), float(ms[2])
+
+    def sizes(self):
+        s = BatchSizes()
+        check(self._lib.km_batch_sizes(self._b, C.byref(s)))
+        return s
+
+    def fetch(self, nodes=True, paths=True):
+        """Copy results to host numpy arrays (dict)."""
+        s = self.sizes()
+        n = s.n_targets
+        r = {
+            "status": np.zeros(n, np.uint32), "n_ref": np.zeros(n, np.uint32),
+            "probes": np.zeros(n, np.uint64), "node_off": np.zeros(n + 1, np.uint64),
+            "logical_probes": int(s.logical_probes), "table_fetches": int(s.table_fetches),
+            "n_big_tier": int(s.n_big_tier),
+        }
+        out = BatchOut()
+        out.status = typed_ptr(r["status"], C.c_uint32)
+        out.n_ref = typed_ptr(r["n_ref"], C.c_uint32)
+        out.probes = typed_ptr(r["probes"], C.c_uint64)
+        out.node_off = typed_ptr(r["node_off"], C.c_uint64)
+        if nodes:
+            r["node_kmer"] = np.zeros(max(1, s.n_nodes), np.uint64)
+            r["node_count"] = np.zeros(max(1, s.n_nodes), np.uint32)
+            out.node_kmer = typed_ptr(r["node_kmer"], C.c_uint64)
+            out.node_count = typed_ptr(r["node_count"], C.c_uint32)
+        if paths:
+            r["path_off"] = np.zeros(n + 1, np.uint32)
+            r["run_off"] = np.zeros(s.n_paths + 1, np.uint64)
+            r["run_start"] = np.zeros(max(1, s.n_runs), np.uint32)
+            r["run_len"] = np.zeros(max(1, s.n_runs), np.uint32)
+            r["path_len"] = np.zeros(max(1, s.n_paths), np.uint32)
+            r["path_min_cov"] = np.zeros(max(1, s.n_paths), np.uint32)
+            out.path_off = typed_ptr(r["path_off"], C.c_uint32)
+            out.run_off = typed_ptr(r["run_off"], C.c_uint64)
+            out.run_start = typed_ptr(r["run_start"], C.c_uint32)
+            out.run_len = typed_ptr(r["run_len"], C.c_uint32)
+            out.path_len = typed_ptr(r["path_len"], C.c_uint32)
+            out.path_min_cov = typed_ptr(r["path_min_cov"], C.c_uint32)
+        check(self._lib.km_batch_fetch(self._b, C.byref(out)))
+        if nodes:
+            r["node_kmer"] = r["node_kmer"][: s.n_nodes]
+            r["node_count"] = r["node_count"][: s.n_nodes]
+        if paths:
+            r["run_start"] = r["run_start"][: s.n_runs]
+            r["run_len"] = r["run_len"][: s.n_runs]
+            r["path_len"] = r["path_len"][: s.n_paths]
+            r["path_min_cov"] = r["path_min_cov"][: s.n_paths]
+        return r
+
+
+def expand_path(res, p):
+    """Node indices of path `p` (global path number) from the run-length records."""
+    a, b = int(res["run_off"][p]), int(res["run_off"][p + 1])
+    if b == a:
+        return np.zeros(0, np.int64)
+    return np.concatenate([np.arange(s, s + l, dtype=np.int64)
+                           for s, l in zip(res["run_start"][a:b].tolist(),
+                                           res["run_len"][a:b].tolist())])

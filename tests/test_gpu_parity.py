@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and
+the committed golden vectors.  Bit-exact: integer / index / byte work throughout;
+the TSV's floating-point columns come from identical numpy calls on the host."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from km_amd import kmer as km
+from km_amd import lib as kmlib
+from km_amd import report, synth
+from km_amd.finder import BatchFinder, NodeLimitExceeded
+from km_amd.jellyfish import Jellyfish
+from oracle import jf_reader as jr
+from oracle import km_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+DBS = ["02H025_NPM1.jf", "02H033_DNMT3A_sub.jf", "03H112_IandI.jf", "03H116_ITD.jf",
+       "05H094_FLT3-TKD_del.jf"]
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(autouse=True)
+def _cwd(monkeypatch):
+    monkeypatch.chdir(HERE)
+
+
+def _gpu_lines(targets, db_path, count=5, ratio=0.05, steps=500, branchs=10, nodes=10000):
+    """What `km find_mutation` prints (minus the elapsed trailer), via the GPU path."""
+    lines = ["#count:%s" % count, "#ratio:%s" % ratio, "#steps:%s" % steps,
+             "#branchs:%s" % branchs, "#nodes:%s" % nodes, "#graphical:False",
+             "#verbose:False", "#debug:False", "#target_fn:%s" % (list(targets),),
+             "#jellyfish_fn:%s" % db_path, report.HEADER]
+    jf = Jellyfish(db_path, cutoff=ratio, n_cutoff=count)
+    tg = [(os.path.splitext(os.path.basename(t))[0], ko.read_fasta_concat(t)) for t in targets]
+    err = None
+    for res in BatchFinder(jf, steps, branchs, nodes).analyse(tg):
+        if isinstance(res, NodeLimitExceeded):
+            err = str(res)
+            break
+        lines += report.target_rows(res, db_path)
+    return lines, err
+
+
+# ------------------------------------------------------------------ lookups
+def test_min_cov_known_answers_gpu():
+    """km/tests/test_main.py:581-652 through kmjf_query_batch."""
+    seq = ko.read_fasta_concat("./data/catalog/GRCh38/FLT3-ITD_exons_13-15.fa")
+    c = Jellyfish("./data/jf/02H025_NPM1.jf").query_seq(seq)
+    assert (int(c.sum()), len(c), int((c == 0).sum())) == (0, 315, 315)
+    c = Jellyfish("./data/jf/03H112_IandI.jf").query_seq(seq).astype(np.int64)
+    assert (int(c.sum()), int(c.min()), int(c.max()), len(c), int((c == 0).sum())) == \
+        (275596, 618, 1368, 315, 0)
+    assert "%.2f" % (c.sum() / len(c)) == "874.91"
+
+
+def test_query_every_record_and_absent_keys():
+    rng = np.random.default_rng(1)
+    for name in DBS:
+        d = jr.read_jf("./data/jf/" + name)
+        jf = Jellyfish("./data/jf/" + name)
+        assert jf.k == 31 and jf.canonical
+        got = jf.query_many(d["keys"])
+        assert (got == d["counts"]).all()
+        got = jf.query_many(jr.revcomp_np(d["keys"], 31))          # other strand
+        assert (got == d["counts"]).all()
+        absent = rng.integers(0, 1 << 62, size=5000, dtype=np.uint64)
+        table = dict(zip(d["keys"].tolist(), d["counts"].tolist()))
+        want = np.array([table.get(jr.canonical(int(x), 31), 0) for x in absent], dtype=np.uint32)
+        assert (jf.query_many(absent) == want).all()
+
+
+def test_get_child_golden_vectors():
+    for case in _load("fixtures_children.json")["cases"]:
+        jf = Jellyfish(case["db"], cutoff=case["ratio"], n_cutoff=case["count"])
+        seqs = [c[0] for c in case["children"]]
+        packed = np.array([km.pack_str(s) for s in seqs], dtype=np.uint64)
+        counts = jf.query_many(packed)
+        mask, _ = jf.children_many(packed)
+        for i, (seq, cnt, kids) in enumerate(case["children"]):
+            assert int(counts[i]) == cnt
+            got = [seq[1:] + b for c, b in enumerate("ACGT") if (int(mask[i]) >> c) & 1]
+            assert got == kids
+        # scalar drop-in API on a few
+        for seq, cnt, kids in case["children"][:4]:
+            assert jf.query(seq) == cnt and jf.get_child(seq) == kids
+
+
+def test_children_backward_matches_oracle():
+    d = jr.read_jf("./data/jf/03H116_ITD.jf")
+    db = ko.KmerDB("./data/jf/03H116_ITD.jf", cutoff=0.05, n_cutoff=5)
+    jf = Jellyfish("./data/jf/03H116_ITD.jf", cutoff=0.05, n_cutoff=5)
+    seqs = [jr.unpack(x, 31) for x in d["keys"][:200]]
+    for s in seqs[:50]:
+        assert jf.get_child(s, forward=False) == db.get_child(s, forward=False)
+
+
+# ------------------------------------------------------------------ walk + graph
+def _compare_with_oracle(jf_gpu, db_cpu, targets, steps=500, branchs=10, nodes=10000):
+    finder = BatchFinder(jf_gpu, steps, branchs, nodes)
+    got = finder.analyse(targets)
+    for (name, seq), g in zip(targets, got):
+        try:
+            want = ko.analyse_target(seq, name, db_cpu, steps, branchs, nodes)
+        except ko.NodeLimit:
+            assert isinstance(g, NodeLimitExceeded), name
+            continue
+        assert not isinstance(g, Exception), (name, g)
+        assert g.n_ref == want["n_ref"], name
+        assert [km.unpack(x, jf_gpu.k) for x in g.kmers] == want["kmers"], name
+        assert g.counts.tolist() == want["counts"], name
+        assert g.probes == want["probes"], name
+        assert [p.tolist() for p in g.paths] == [list(p) for p in want["paths"]], name
+        assert list(g.min_cov) == want["min_cov"], name
+    return got
+
+
+@pytest.mark.parametrize("db", DBS)
+def test_catalog_walk_and_paths_match_oracle(db):
+    cat = sorted(os.listdir("./data/catalog/GRCh38"))
+    targets = [(os.path.splitext(f)[0], ko.read_fasta_concat("./data/catalog/GRCh38/" + f))
+               for f in cat]
+    jf = Jellyfish("./data/jf/" + db, cutoff=0.05, n_cutoff=5)
+    cpu = ko.KmerDB("./data/jf/" + db, cutoff=0.05, n_cutoff=5)
+    _compare_with_oracle(jf, cpu, targets)
+
+
+def test_walk_golden_vectors_from_reference():
+    """Node sets / probe counts / path sequences / min coverages produced by the
+    unmodified reference (tests/golden/fixtures_walk.json)."""
+    for case in _load("fixtures_walk.json")["cases"]:
+        jf = Jellyfish(case["db"], cutoff=0.05, n_cutoff=5)
+        targets = [(g["name"], ko.read_fasta_concat(fa))
+                   for fa, g in zip(case["targets_fa"], case["targets"])]
+        for g, r in zip(case["targets"], BatchFinder(jf).analyse(targets)):
+            assert len(r.kmers) + 2 == g["num_k"]
+            nodes = sorted([km.unpack(x, 31), int(c)] for x, c in zip(r.kmers, r.counts))
+            assert nodes == g["nodes"]
+            assert r.probes in g["probes_seen"]
+            tails = r.last_bases()
+            seqs = sorted(r.spell(p, tails) for p in r.paths)
+            assert seqs == g["path_seqs"]
+            by = {r.spell(p, tails): m for p, m in zip(r.paths, r.min_cov)}
+            assert [by[s] for s in seqs] == g["path_min_cov"]
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_fixture_tsv_bit_identical(idx):
+    case = _load("fixtures_tsv.json")["cases"][idx]
+    lines, err = _gpu_lines(case["targets"], case["db"])
+    assert err == case["exit"]
+    assert lines == case["lines"]
+
+
+_norm = lambda l: re.sub(r"cluster \d+ n=", "cluster * n=", l)
+
+
+@pytest.mark.parametrize("idx", range(len(synth.GOLDEN_SPECS)))
+def test_synthetic_slices(idx, tmp_path, monkeypatch):
+    case = _load("synth_tsv.json")["cases"][idx]
+    spec = case["spec"]
+    fas, dbp, meta = synth.write_case(str(tmp_path), **spec)
+    assert meta["md5"] == case["input_md5"]
+    monkeypatch.chdir(tmp_path)
+    rel = [os.path.relpath(f, str(tmp_path)) for f in fas]
+    reldb = os.path.relpath(dbp, str(tmp_path))
+    prm = spec.get("params", {})
+    # (1) against the oracle: nodes, counts, probes, paths, min_cov — exact
+    jf = Jellyfish(reldb, cutoff=0.05, n_cutoff=5)
+    cpu = ko.KmerDB(reldb, cutoff=0.05, n_cutoff=5)
+    targets = [(os.path.splitext(os.path.basename(f))[0], ko.read_fasta_concat(f)) for f in rel]
+    _compare_with_oracle(jf, cpu, targets, prm.get("steps", 500), prm.get("branchs", 10),
+                         prm.get("nodes", 10000))
+    # (2) against the reference's TSV
+    lines, err = _gpu_lines(rel, reldb, **prm)
+    assert err == case["exit"]
+    if case["stable"]:
+        assert lines == case["lines"]
+    else:
+        assert sorted(map(_norm, lines)) == sorted(map(_norm, case["lines"]))
+    # (3) and line for line against the oracle's TSV
+    want, werr = ko.run_find_mutation(rel, reldb, **prm)
+    assert (lines, err) == (want, werr)
+
+
+def test_large_tier_matches_oracle(tmp_path):
+    """Targets that outgrow the LDS-resident tier (many long insertions) take the
+    global-workspace kernels; results must not change."""
+    case = synth.make_case(n_targets=6, length=700, n_keys=20000, seed=77, variant_frac=1.0,
+                           variants_per_target=(9, 11), kinds=("ins", "dup"), vaf=(0.3, 0.5))
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                    records={"k": 31, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+    targets = [(n, km.decode(r)) for n, r in zip(case["names"], case["targets"])]
+    finder = BatchFinder(jf)
+    raw = finder.run_raw([t[1] for t in targets])
+    assert raw["n_big_tier"] > 0
+    _compare_with_oracle(jf, cpu, targets)
+
+
+def test_error_statuses():
+    jf = Jellyfish("./data/jf/02H025_NPM1.jf", cutoff=0.05, n_cutoff=5)
+    f = BatchFinder(jf)
+    with pytest.raises(ValueError, match="found multiple times in reference polyA, at pos. 1"):
+        f.analyse([("polyA", "A" * 32)])                 # km/tests/test_main.py:555-561
+    with pytest.raises(AssertionError):
+        f.analyse([("short", "ACGT")])
+    with pytest.raises(ValueError):
+        f.analyse([("n", "ACGTN" * 10)])
+    raw = f.run_raw(["A" * 32, "ACGT", "ACGTN" * 10,
+                     ko.read_fasta_concat("./data/catalog/GRCh38/NPM1_4ins_exons_10-11utr.fa")])
+    assert raw["status"].tolist() == [kmlib.T_REPEAT_KMER, kmlib.T_EMPTY, kmlib.T_BAD_BASE, kmlib.T_OK]
+
+
+def test_empty_batch_and_ragged():
+    jf = Jellyfish("./data/jf/03H116_ITD.jf", cutoff=0.05, n_cutoff=5)
+    f = BatchFinder(jf)
+    assert f.analyse([]) == []
+    seq = ko.read_fasta_concat("./data/catalog/GRCh38/FLT3-ITD_exons_13-15.fa")
+    cpu = ko.KmerDB("./data/jf/03H116_ITD.jf", cutoff=0.05, n_cutoff=5)
+    ragged = [("t%d" % i, seq[i:i + L]) for i, L in enumerate([31, 32, 63, 64, 65, 95, 96, 97, 200, 345])]
+    _compare_with_oracle(jf, cpu, ragged)
+    # budgets at their edges
+    for steps, br, nodes in [(0, 10, 10000), (1, 10, 10000), (2, 0, 10000), (70, 1, 10000),
+                             (500, 10, 315), (500, 10, 316), (500, 10, 346), (500, 10, 347)]:
+        _compare_with_oracle(jf, cpu, [("flt3", seq)], steps, br, nodes)
