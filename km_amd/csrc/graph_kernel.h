@@ -173,6 +173,8 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
       pred[4 * j + c] = u;
     }
   }
+  // the capping nodes have no overlap edges (their two cap edges are handled apart)
+  if (lane < 8) { succ[4 * m + lane] = NONE; pred[4 * m + lane] = NONE; }
   __syncthreads();
 
   // ---- 3. exact distances: frontier Dijkstra, forward from source, backward from sink
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
       // relax: lanes 0..3 the overlap edges, lane 4 the cap edge
       uint32_t v = 0;
       bool have = false;
-      if (lane < 4) {
+      if (lane < 4 && u < m) {              // caps are sinks of their own pass: never expanded
         const idx_t x = adj[4 * u + lane];
         if (x != NONE) { v = x; have = true; }
       } else if (lane == 4) {
