@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Benchmark of the find_mutation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[3]): per GPU 10 000 random
+500-nt targets, k=31, against ONE table of 100 M distinct canonical 31-mers
+resident in HBM.  A step = one pass of the hot path (walk kernel + path-search
+kernel) over the GPU's 10 000 targets; targets and table are in HBM before the
+timed region starts.  With N > 1 the table records are broadcast once over RCCL
+(torch.distributed) and every rank builds its own table; targets are sharded by
+rank, no further collectives (weak scaling: per-GPU work fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_PROBE = 12           # 8-byte key + 4-byte count
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(case, n_sample, k):
+    """The oracle (structure-faithful Python restatement of the reference path)
+    timed on one host core over the first `n_sample` targets of this workload."""
+    from km_amd import kmer as km
+    from oracle import km_oracle as ko
+    nr = case["n_real"]
+    # the first n_real records are the non-pad keys; random pad 31-mers never touch
+    # these targets' walks, so the oracle only needs the real ones
+    rec = {"k": k, "canonical": True, "keys": case["keys"][:nr], "counts": case["counts"][:nr]}
+    db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records=rec)
+    t0 = time.perf_counter()
+    probes = 0
+    rows = 0
+    for i in range(n_sample):
+        seq = km.decode(case["targets"][i])
+        res = ko.analyse_target(seq, case["names"][i], db)
+        probes += res["probes"]
+        rows += len(res["paths"])
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "targets/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the 10000 targets (walk + path search, oracle/km_oracle.py, "
+                      "dict-backed table of the %d non-pad keys)" % (n_sample, nr),
+            "probes_per_s": probes / dt, "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--targets", type=int, default=10000, help="targets per GPU")
+    ap.add_argument("--length", type=int, default=500)
+    ap.add_argument("--keys", type=int, default=100_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=300)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify a sample against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from km_amd import lib as kmlib
+    from km_amd import synth
+
+    K = 31
+    T = args.targets
+    # ---- rank 0 generates the whole job: world*T targets, one table --------------------
+    t_gen = time.perf_counter()
+    if rank == 0:
+        case = synth.make_case(n_targets=T * world, length=args.length, k=K, n_keys=args.keys,
+                               seed=synth.HEADLINE_SEED, exact_pad=False)
+        n_rec = int(case["keys"].size)
+        meta = torch.tensor([n_rec], dtype=torch.int64, device=dev)
+    else:
+        case = None
+        meta = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(meta, 0)
+    n_rec = int(meta.item())
+    t_gen = time.perf_counter() - t_gen
+
+    # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------
+    t_up = time.perf_counter()
+    if rank == 0:
+        d_keys = torch.from_numpy(case["keys"].view(np.int64)).to(dev)
+        d_cnts = torch.from_numpy(case["counts"].view(np.int32)).to(dev)
+        bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(dev)
+    else:
+        d_keys = torch.empty(n_rec, dtype=torch.int64, device=dev)
+        d_cnts = torch.empty(n_rec, dtype=torch.int32, device=dev)
+        bases_all = torch.empty((T * world, args.length), dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.broadcast(d_keys, 0)
+        dist.broadcast(d_cnts, 0)
+        dist.broadcast(bases_all, 0)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t_up
+    t_build = time.perf_counter()
+    db = kmlib.Database.empty(K, True)
+    stream = torch.cuda.current_stream().cuda_stream
+    db.upload_from_device(local_rank, d_keys.data_ptr(), d_cnts.data_ptr(), n_rec, stream)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    info = db.info
+    del d_keys, d_cnts
+    torch.cuda.empty_cache()
+
+    # ---- this rank's shard of targets, resident in HBM -----------------------------------
+    mine = bases_all[rank * T:(rank + 1) * T].contiguous()
+    offsets = (np.arange(T + 1, dtype=np.uint64) * np.uint64(args.length))
+    batch = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
+                        max_targets=T, max_total_bases=T * args.length)
+    batch.set_targets_dev(mine.data_ptr(), offsets, stream)
+    both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+
+    # ---- warm-up ---------------------------------------------------------------------------
+    for _ in range(max(1, args.warmup)):
+        batch.run(both, stream)
+    batch.sync()
+    sizes = batch.sizes()
+    probes_per_step = int(sizes.logical_probes)
+    fetches_per_step = int(sizes.table_fetches)
+
+    # ---- timed region: exactly K steps ----------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run(both, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    batch.sync()
+
+    # ---- per-kernel durations (HIP events on the launch stream), averaged over K launches
+    walk_ms, graph_ms = [], []
+    for _ in range(args.steps):
+        batch.run(both, stream)
+        w, g, _tot = batch.timings()
+        walk_ms.append(w)
+        graph_ms.append(g)
+    walk_avg = float(np.mean(walk_ms))
+    graph_avg = float(np.mean(graph_ms))
+
+    # ---- result fetch (D2H + host reorganisation), reported beside the kernel rate ----------
+    t_f = time.perf_counter()
+    res = batch.fetch()
+    fetch_s = time.perf_counter() - t_f
+
+    if args.check and rank == 0:
+        from km_amd import kmer as km
+        from oracle import km_oracle as ko
+        nr = case["n_real"]
+        cpu = ko.KmerDB(None, 0.05, 5, records={"k": K, "canonical": True,
+                                                "keys": case["keys"][:nr], "counts": case["counts"][:nr]})
+        for t in range(0, T, max(1, T // 50)):
+            want = ko.analyse_target(km.decode(case["targets"][t]), "t", cpu)
+            a, e = int(res["node_off"][t]), int(res["node_off"][t + 1])
+            assert [km.unpack(x, K) for x in res["node_kmer"][a:e]] == want["kmers"], t
+            assert res["node_count"][a:e].tolist() == want["counts"], t
+            pa, pe = int(res["path_off"][t]), int(res["path_off"][t + 1])
+            assert [kmlib.expand_path(res, p).tolist() for p in range(pa, pe)] == \
+                [list(p) for p in want["paths"]], t
+        log("check ok")
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * T / (dt / args.steps)
+        walk_s = walk_avg * 1e-3
+        achieved = probes_per_step * BYTES_PER_PROBE / walk_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_walk_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "find_mutation_targets_per_sec",
+            "value": value,
+            "unit": "targets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic_%dx%dnt_targets_per_gpu_%dM_kmer_table_k31"
+                                   % (T, args.length, round(n_rec / 1e6)),
+                       "targets_per_gpu": T, "target_len": args.length, "k": K,
+                       "table_keys": n_rec, "table_bytes": int(info.table_bytes),
+                       "params": "-c 5 -p 0.05 -s 500 -b 10 -n 10000",
+                       "parallelism": "target-sharded x%d, table replicated (1 RCCL broadcast)" % world},
+            "gprobes_per_s": world * probes_per_step / (dt / args.steps) / 1e9,
+            "logical_probes_per_step": probes_per_step,
+            "table_fetches_per_step": fetches_per_step,
+            "kernel_ms": {"walk": walk_avg, "graph": graph_avg},
+            "result_fetch_ms": fetch_s * 1e3,
+            "setup_s": {"generate": t_gen, "h2d_broadcast": t_bcast, "table_build": t_build},
+            "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": probes_per_step * BYTES_PER_PROBE,
+                         "physical_fetch_bytes_per_launch": fetches_per_step * 32},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(case, min(args.cpu_sample, T), K)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,7 +60,8 @@ def _mutate(rng, row, kind, k):
 def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEED,
               variant_frac=0.30, variants_per_target=(1, 1), vaf=(0.1, 0.6),
               kinds=("snv", "ins", "del", "dup"), noise_frac=0.01, noise_counts=(2, 5),
-              cov=(50, 2000), hom_frac=0.0, branch_noise_frac=0.0, name=None, **_):
+              cov=(50, 2000), hom_frac=0.0, branch_noise_frac=0.0, name=None,
+              exact_pad=True, **_):
     """Build targets + (keys, counts).  Returns dict(targets=uint8[n,L] codes,
     names, keys uint64 (canonical, distinct), counts uint32, k)."""
     rng = np.random.default_rng(seed)
@@ -121,8 +122,26 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
     uk, first = np.unique(keys, return_index=True)          # first occurrence wins
     keys, cnts = uk, cnts[first]
 
+    n_real = int(keys.size)
     n_pad = max(0, n_keys - keys.size)
-    if n_pad:
+    if n_pad and not exact_pad:
+        # headline-size tables: skip the 100M-key sort; random 62-bit pads are distinct
+        # with overwhelming probability, the rare one equal to a real key is dropped
+        chunks_k, chunks_c = [keys], [cnts]
+        left = n_pad
+        while left > 0:
+            m = min(left, 1 << 24)
+            hi = (1 << (2 * k)) if 2 * k < 64 else int(np.iinfo(np.uint64).max)
+            pad = km.canonical(rng.integers(0, hi, size=m, dtype=np.uint64), k)
+            pos = np.searchsorted(keys, pad)
+            pos[pos >= keys.size] = keys.size - 1
+            ok = keys[pos] != pad
+            chunks_k.append(pad[ok])
+            chunks_c.append(rng.integers(2, 51, size=m)[ok])
+            left -= m
+        keys = np.concatenate(chunks_k)
+        cnts = np.concatenate(chunks_c)
+    elif n_pad:
         pad = km.canonical(rng.integers(0, 1 << (2 * k), size=n_pad, dtype=np.uint64)
                            if 2 * k < 64 else rng.integers(0, np.iinfo(np.uint64).max, size=n_pad,
                                                            dtype=np.uint64), k)
@@ -133,7 +152,7 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
         keys, cnts = uk, cnts[first]
     names = ["%s%05d" % ((name or "syn") + "_t", i) for i in range(n_targets)]
     return {"targets": rows, "names": names, "keys": keys.astype(np.uint64),
-            "counts": np.minimum(cnts, 0xFFFFFFFF).astype(np.uint32), "k": k}
+            "counts": np.minimum(cnts, 0xFFFFFFFF).astype(np.uint32), "k": k, "n_real": n_real}
 
 
 def write_jf(path, keys, counts, k, canonical=True):
