@@ -9,11 +9,19 @@
 // BigBang (source) = m, BigCrunch (sink) = m + 1 with m = n_nodes.
 //
 // How the dense O(n^2) algorithm is reproduced exactly on a sparse graph:
+//  * edges   One LDS table keyed by the (k-1)-mer PREFIX of every node holds the
+//    node index per last base; the suffix of node j looked up there yields its
+//    <=4 successors in one probe (the reference's prefix_dct), predecessors are
+//    the transposed scatter (a predecessor is identified by its first base).
 //  * dist[]  With strictly positive weights and monotone float32 addition the
 //    distances Dijkstra ends with are the unique solution of
-//    dist[j] = min_i fl(dist[i] + w_ij); any label-setting order yields them.  A
-//    frontier Dijkstra over the <=4 successors (predecessors) per node computes
-//    them with the same float32 additions (hop by hop along the path).
+//    dist[j] = min_i fl(dist[i] + w_ij); any label-setting order that relaxes
+//    every edge with the final distance of its tail yields them, with the same
+//    float32 additions hop by hop.  These graphs are long index-contiguous
+//    chains (node j -> j+1 being j's only out-edge and j+1's only in-edge: the
+//    "link" bitmap), so a frontier Dijkstra only runs over chain heads; a whole
+//    chain is finalised by a register loop of dependent float adds with one LDS
+//    write per 64 nodes.
 //  * prev[]  Graph.py visits nodes in (dist, index) order and overwrites prev[j]
 //    only on a strict improvement, hence prev[j] is the in-neighbour i minimising
 //    (fl(dist[i] + w_ij), dist[i], i) lexicographically — a purely local rule
@@ -26,7 +34,8 @@
 //    usual case), no path materialisation or hashing needed.
 //
 // Paths leave the kernel run-length encoded (consecutive node indices collapse
-// to (start, len)) into pools reserved with one atomicAdd per target.
+// to (start, len)); emission hops from chain to chain through the link bitmap.
+// Pool space is reserved with one atomicAdd per target.
 #pragma once
 #include <type_traits>
 
@@ -38,6 +47,7 @@ namespace kmd {
 struct GraphArgs {
   int k;
   uint64_t kmask;
+  uint64_t pmask;
   const uint32_t* tids;      // BIG: targets to run; nullptr = blockIdx.x
   uint32_t n_targets;
   const uint64_t* node_kmer;
@@ -61,41 +71,33 @@ struct GraphArgs {
   uint32_t* r_len;
   // geometry
   uint32_t ncap;   // max nodes incl. caps
-  uint32_t hcap;   // hash slots, multiple of 64, >= 2 * ncap
+  uint32_t hcap;   // prefix-table slots, multiple of 64, >= 1.5 * ncap
   unsigned char* g_ws;
   uint64_t g_stride;
 };
 
 template <typename idx_t>
-__host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap) {
-  uint64_t b = 0;
-  b += (uint64_t)hcap * 8;                 // keys
-  b += (uint64_t)ncap * 4 * 3;             // dist_f, dist_b, cnt
-  b += (uint64_t)((ncap + 31) / 32) * 4;   // inq bits
-  b += (uint64_t)((4 * (uint64_t)ncap + 2 + 31) / 32) * 4;  // removed bits
-  b += 16;                                 // scalars
-  b += (uint64_t)hcap * sizeof(idx_t);     // hash -> node index
-  b += (uint64_t)ncap * 4 * sizeof(idx_t) * 2;  // succ, pred
-  b += (uint64_t)ncap * sizeof(idx_t) * 3;      // before, after, frontier
-  b += (uint64_t)ncap * 2 * sizeof(idx_t);      // candidate edges (a, b)
-  return (b + 15) & ~15ull;
+__host__ __device__ inline uint64_t graph_region_a(uint32_t ncap, uint32_t hcap) {
+  const uint64_t tab = (uint64_t)hcap * (8 + 4 * sizeof(idx_t));   // prefix keys + 4 indices
+  const uint64_t run = (uint64_t)ncap * (8 + 5 * sizeof(idx_t));   // dist_f/b, before, after, frontier, cand(2)
+  return ((tab > run ? tab : run) + 15) & ~15ull;
 }
 
-__device__ inline int hash_find_lane(const uint64_t* keys, uint32_t cap, uint64_t key) {
-  uint32_t s = set_home(key, cap);
-  for (uint32_t step = 0; step < cap; ++step) {
-    const uint64_t kv = keys[s];
-    if (kv == key) return (int)s;
-    if (kv == EMPTY) return -1;
-    if (++s == cap) s = 0;
-  }
-  return -1;
+template <typename idx_t>
+__host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap) {
+  uint64_t b = graph_region_a<idx_t>(ncap, hcap);
+  b += (((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull;  // succ, pred
+  b += (uint64_t)((ncap + 31) / 32) * 4 * 2;                  // link, inq bits
+  b += (uint64_t)((4 * (uint64_t)ncap + 2 + 31) / 32) * 4;    // removed bits
+  b += 32;                                                    // scalars
+  return (b + 15) & ~15ull;
 }
 
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
   constexpr idx_t NONE = (idx_t)~(idx_t)0;
+  constexpr uint32_t NIL = 0xFFFFFFFFu;
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t lane = (uint32_t)lane_id();
   const uint32_t t = a.tids ? a.tids[blockIdx.x] : blockIdx.x;
@@ -108,33 +110,40 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   const uint32_t n_ref = a.n_ref[t];
   const uint32_t n = m + 2, src = m, snk = m + 1;
   const uint32_t ncap = a.ncap, hcap = a.hcap;
-  if (n > ncap || (uint64_t)2 * n > hcap || (!BIG && n >= 0xFFFFu)) {
+  if (n > ncap || (uint64_t)3 * n > (uint64_t)2 * hcap || (!BIG && n >= 0xFFFFu)) {
     if (lane == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
   const uint64_t nb = a.node_base[t];
   const uint64_t* nk = a.node_kmer + nb;
+  const uint32_t* ncnt = a.node_cnt + nb;
   const int k = a.k;
 
   unsigned char* wsb;
   if constexpr (BIG) wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
   else wsb = smem;
-  uint64_t* keys = reinterpret_cast<uint64_t*>(wsb);
-  float* dist_f = reinterpret_cast<float*>(keys + hcap);
+  // region A, first life: prefix table
+  uint64_t* pkeys = reinterpret_cast<uint64_t*>(wsb);
+  idx_t* pidx = reinterpret_cast<idx_t*>(pkeys + hcap);
+  // region A, second life
+  float* dist_f = reinterpret_cast<float*>(wsb);
   float* dist_b = dist_f + ncap;
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(dist_b + ncap);
-  uint32_t* inq = cnt + ncap;
-  uint32_t* removed = inq + (ncap + 31) / 32;
-  const uint32_t n_removed_words = (uint32_t)((4 * (uint64_t)ncap + 2 + 31) / 32);
-  uint32_t* scal = removed + n_removed_words;      // [0] candidate count, [1] flag
-  idx_t* hidx = reinterpret_cast<idx_t*>(scal + 4);
-  idx_t* succ = hidx + hcap;
-  idx_t* pred = succ + (uint64_t)4 * ncap;
-  idx_t* before = pred + (uint64_t)4 * ncap;
+  idx_t* before = reinterpret_cast<idx_t*>(dist_b + ncap);
   idx_t* after = before + ncap;
   idx_t* frontier = after + ncap;
   idx_t* cand = frontier + ncap;                   // pairs (a, b)
   const uint32_t ccap = ncap;
+  // persistent
+  unsigned char* pp = wsb + graph_region_a<idx_t>(ncap, hcap);
+  idx_t* succ = reinterpret_cast<idx_t*>(pp);
+  idx_t* pred = succ + (uint64_t)4 * ncap;
+  pp += (((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull;
+  const uint32_t nbw = (ncap + 31) / 32;
+  uint32_t* link = reinterpret_cast<uint32_t*>(pp);
+  uint32_t* inq = link + nbw;
+  uint32_t* removed = inq + nbw;
+  const uint32_t n_removed_words = (uint32_t)((4 * (uint64_t)ncap + 2 + 31) / 32);
+  uint32_t* scal = removed + n_removed_words;      // [0] candidate count, [1] pool flag
 
   const float INF = __int_as_float(0x7F800000);
   const float W_REF = 0.01f, W_ALT = 1.0f;
@@ -143,82 +152,133 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     return (u + 1 == v && v < n_ref) ? W_REF : W_ALT;             // reference edge i -> i+1
   };
 
-  // ---- 1. node hash ---------------------------------------------------------------
-  for (uint32_t s = lane; s < hcap; s += 64) keys[s] = EMPTY;
-  for (uint32_t j = lane; j < n; j += 64) { dist_f[j] = INF; dist_b[j] = INF; }
-  for (uint32_t w = lane; w < (ncap + 31) / 32; w += 64) inq[w] = 0;
+  // ---- 1. prefix table: (k-1)-mer prefix -> node index per last base -----------------
+  for (uint32_t s = lane; s < hcap; s += 64) pkeys[s] = EMPTY;
+  for (uint32_t s = lane; s < 4 * hcap; s += 64) pidx[s] = NONE;
+  for (uint32_t s = lane; s < 4 * n; s += 64) { succ[s] = NONE; pred[s] = NONE; }
+  for (uint32_t w = lane; w < nbw; w += 64) { link[w] = 0; inq[w] = 0; }
   for (uint32_t w = lane; w < n_removed_words; w += 64) removed[w] = 0;
-  if (lane < 4) scal[lane] = 0;
+  if (lane < 8) scal[lane] = 0;
   __syncthreads();
-  for (uint32_t j = lane; j < m; j += 64) {
-    bool wn;
-    const int s = set_insert_lane(keys, hcap, nk[j], &wn);
-    if (s >= 0) hidx[s] = (idx_t)j;
-    cnt[j] = a.node_cnt[nb + j];
-  }
-  __syncthreads();
-  // ---- 2. (k-1)-overlap adjacency: succ[4j+c] = node of kmer[j][1:]+c, pred[4j+c] = c+kmer[j][:-1]
   for (uint32_t j = lane; j < m; j += 64) {
     const uint64_t X = nk[j];
-    for (uint32_t c = 0; c < 4; ++c) {
-      const uint64_t child = ((X << 2) | c) & a.kmask;
-      int s = hash_find_lane(keys, hcap, child);
-      idx_t v = (s >= 0) ? hidx[s] : NONE;
-      if (v == (idx_t)j) v = NONE;                               // `if i != j`
-      succ[4 * j + c] = v;
-      const uint64_t par = (X >> 2) | ((uint64_t)c << (2 * (k - 1)));
-      s = hash_find_lane(keys, hcap, par);
-      idx_t u = (s >= 0) ? hidx[s] : NONE;
-      if (u == (idx_t)j) u = NONE;
-      pred[4 * j + c] = u;
+    bool wn;
+    const int s = set_insert_lane(pkeys, hcap, X >> 2, &wn);
+    if (s >= 0) pidx[4 * s + (uint32_t)(X & 3)] = (idx_t)j;
+  }
+  __syncthreads();
+  // ---- 2. adjacency: succ[4j+c] = node of kmer[j][1:]+c ; pred[4v+f] = j, f = first base of j
+  for (uint32_t j = lane; j < m; j += 64) {
+    const uint64_t X = nk[j];
+    const uint64_t S = X & a.pmask;
+    const uint32_t fb = (uint32_t)(X >> (2 * (k - 1))) & 3u;
+    uint32_t s = set_home(S, hcap);
+    for (uint32_t step = 0; step < hcap; ++step) {
+      const uint64_t kv = pkeys[s];
+      if (kv == S) {
+        for (uint32_t c = 0; c < 4; ++c) {
+          const idx_t v = pidx[4 * s + c];
+          if (v != NONE && v != (idx_t)j) {                        // `if i != j`
+            succ[4 * j + c] = v;
+            pred[4 * (uint32_t)v + fb] = (idx_t)j;
+          }
+        }
+        break;
+      }
+      if (kv == EMPTY) break;
+      if (++s == hcap) s = 0;
     }
   }
-  // the capping nodes have no overlap edges (their two cap edges are handled apart)
-  if (lane < 8) { succ[4 * m + lane] = NONE; pred[4 * m + lane] = NONE; }
+  __syncthreads();
+  // ---- 2b. link[j]: j -> j+1 is j's only out-edge and j+1's only in-edge ---------------
+  for (uint32_t base = 0; base < m; base += 64) {
+    const uint32_t j = base + lane;
+    bool lk = false;
+    if (j + 1 < m && j != n_ref - 1) {                            // n_ref-1 also feeds the sink
+      uint32_t outs = 0, ins = 0;
+      bool to_next = false;
+      for (uint32_t c = 0; c < 4; ++c) {
+        const idx_t v = succ[4 * j + c];
+        if (v != NONE) { ++outs; to_next |= (v == (idx_t)(j + 1)); }
+        if (pred[4 * (j + 1) + c] != NONE) ++ins;
+      }
+      lk = (outs == 1) && to_next && (ins == 1);
+    }
+    const unsigned long long bm = __ballot(lk);
+    if (lane == 0) {
+      link[base >> 5] = (uint32_t)bm;
+      if ((base >> 5) + 1 < nbw) link[(base >> 5) + 1] = (uint32_t)(bm >> 32);
+    }
+  }
+  __syncthreads();          // the prefix table is dead from here on: region A is reused
+  for (uint32_t j = lane; j < n; j += 64) { dist_f[j] = INF; dist_b[j] = INF; }
   __syncthreads();
 
-  // ---- 3. exact distances: frontier Dijkstra, forward from source, backward from sink
+  // first index e >= u with link[e] clear (the end of the chain through u)
+  auto chain_end = [&](uint32_t u) -> uint32_t {
+    uint32_t w = u >> 5;
+    uint32_t z = ~link[w] & (0xFFFFFFFFu << (u & 31));
+    while (z == 0 && w + 1 < nbw) { ++w; z = ~link[w]; }           // bit m-1 is always clear
+    return z ? (w << 5) + (uint32_t)__ffs((int)z) - 1 : u;
+  };
+  // lowest s <= v with link[s..v-1] all set (the head of the chain through v)
+  auto chain_head = [&](uint32_t v) -> uint32_t {
+    uint32_t s = v;
+    while (s > 0) {
+      const uint32_t top = (s - 1) & 31, w = (s - 1) >> 5;
+      const uint32_t z = ~link[w] & ((2u << top) - 1u);
+      if (z) { s = (w << 5) + (31 - (uint32_t)__clz((int)z)) + 1; break; }
+      s = w << 5;
+    }
+    return s;
+  };
+
+  // ---- 3. exact distances -------------------------------------------------------------
   for (int dir = 0; dir < 2; ++dir) {
     float* dist = dir ? dist_b : dist_f;
     const idx_t* adj = dir ? pred : succ;
     uint32_t fcount = 0;
-    for (uint32_t w = lane; w < (ncap + 31) / 32; w += 64) inq[w] = 0;
-    if (lane == 0) {
-      if (dir == 0) { dist[src] = 0.0f; dist[0] = 0.0f + W_REF; frontier[0] = (idx_t)0; }
-      else { dist[snk] = 0.0f; dist[n_ref - 1] = 0.0f + W_REF; frontier[0] = (idx_t)(n_ref - 1); }
-    }
-    fcount = 1;
+    uint32_t cur = dir ? n_ref - 1 : 0;
+    float d = 0.0f + W_REF;                                         // cap edge from the root
+    if (dir == 1) { for (uint32_t w = lane; w < nbw; w += 64) inq[w] = 0; }
+    if (lane == 0) { dist[dir ? snk : src] = 0.0f; dist[cur] = d; }
     __syncthreads();
     uint32_t guard = 0;
-    while (fcount > 0 && guard++ <= n) {
-      // select the frontier entry with the smallest distance
-      uint32_t pos = 0;
-      if (fcount > 1) {
-        unsigned long long best = ~0ull;
-        for (uint32_t base = 0; base < fcount; base += 64) {
-          const uint32_t p = base + lane;
-          unsigned long long key = ~0ull;
-          if (p < fcount)
-            key = ((unsigned long long)__float_as_uint(dist[frontier[p]]) << 32) | p;
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o);
-            key = other < key ? other : key;
+    while (guard++ <= n) {
+      // (cur, d) is final: run along its chain in registers
+      uint32_t end;
+      if (dir == 0) {
+        end = chain_end(cur);
+        uint32_t j = cur;
+        while (j < end) {
+          const uint32_t cnt = (end - j < 64u) ? end - j : 64u;
+          float keep = 0.0f;
+          for (uint32_t q = 0; q < cnt; ++q) {
+            d = d + ((j + q + 1 < n_ref) ? W_REF : W_ALT);          // edge (j+q) -> (j+q+1)
+            if (q == lane) keep = d;
           }
-          best = key < best ? key : best;
+          if (lane < cnt) dist[j + 1 + lane] = keep;
+          j += cnt;
         }
-        pos = (uint32_t)(best & 0xFFFFFFFFu);
+      } else {
+        end = chain_head(cur);
+        uint32_t j = cur;
+        while (j > end) {
+          const uint32_t cnt = (j - end < 64u) ? j - end : 64u;
+          float keep = 0.0f;
+          for (uint32_t q = 0; q < cnt; ++q) {
+            d = d + ((j - q < n_ref) ? W_REF : W_ALT);              // edge (j-q-1) -> (j-q)
+            if (q == lane) keep = d;
+          }
+          if (lane < cnt) dist[j - 1 - lane] = keep;
+          j -= cnt;
+        }
       }
-      const uint32_t u = frontier[pos];
-      const float du = dist[u];
-      __syncthreads();
-      if (lane == 0) {
-        frontier[pos] = frontier[fcount - 1];
-      }
-      --fcount;
-      // relax: lanes 0..3 the overlap edges, lane 4 the cap edge
+      const uint32_t u = end;
+      // relax the edges leaving the chain: lanes 0..3 overlap edges, lane 4 the cap edge
       uint32_t v = 0;
       bool have = false;
-      if (lane < 4 && u < m) {              // caps are sinks of their own pass: never expanded
+      if (lane < 4 && u < m) {
         const idx_t x = adj[4 * u + lane];
         if (x != NONE) { v = x; have = true; }
       } else if (lane == 4) {
@@ -227,39 +287,58 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
       }
       bool push = false;
       if (have) {
-        const float w = dir ? weight(v, u) : weight(u, v);
-        const float nd = du + w;
+        const float nd = d + (dir ? weight(v, u) : weight(u, v));
         if (nd < dist[v]) {
           dist[v] = nd;
-          const uint32_t bit = 1u << (v & 31);
-          if (!(inq[v >> 5] & bit)) { push = true; }
+          // caps are never expanded; other nodes enter the frontier once
+          if (v < m && !((inq[v >> 5] >> (v & 31)) & 1u)) push = true;
         }
       }
-      __syncthreads();
       const unsigned long long pm = __ballot(push);
       if (push) {
-        const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1));
-        frontier[fcount + rank] = (idx_t)v;
+        frontier[fcount + (uint32_t)__popcll(pm & ((1ull << lane) - 1))] = (idx_t)v;
         atomicOr(&inq[v >> 5], 1u << (v & 31));
       }
       fcount += (uint32_t)__popcll(pm);
+      __syncthreads();
+      if (fcount == 0) break;
+      // extract the frontier entry with the smallest distance
+      uint32_t pos = 0;
+      if (fcount > 1) {
+        unsigned long long best = ~0ull;
+        for (uint32_t base = 0; base < fcount; base += 64) {
+          const uint32_t p = base + lane;
+          unsigned long long key = ~0ull;
+          if (p < fcount) key = ((unsigned long long)__float_as_uint(dist[frontier[p]]) << 32) | p;
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other < key ? other : key;
+          }
+          best = key < best ? key : best;
+        }
+        pos = (uint32_t)(best & 0xFFFFFFFFu);
+      }
+      cur = frontier[pos];
+      d = dist[cur];
+      __syncthreads();
+      if (lane == 0) frontier[pos] = frontier[fcount - 1];
+      --fcount;
       __syncthreads();
     }
   }
 
   // ---- 4. predecessor arrays by the local rule ------------------------------------
   for (uint32_t j = lane; j < n; j += 64) {
-    // before[j]: in-neighbour minimising (dist_f[u] + w(u,j), dist_f[u], u)
     {
       idx_t best = NONE;
       float bv = INF, bd = INF;
       if (j != src && dist_f[j] < INF) {
         auto consider = [&](uint32_t u) {
-          const float d = dist_f[u];
-          if (!(d < INF)) return;
-          const float val = d + weight(u, j);
-          if (best == NONE || val < bv || (val == bv && (d < bd || (d == bd && u < (uint32_t)best)))) {
-            best = (idx_t)u; bv = val; bd = d;
+          const float du = dist_f[u];
+          if (!(du < INF)) return;
+          const float val = du + weight(u, j);
+          if (best == NONE || val < bv || (val == bv && (du < bd || (du == bd && u < (uint32_t)best)))) {
+            best = (idx_t)u; bv = val; bd = du;
           }
         };
         if (j == snk) consider(n_ref - 1);
@@ -275,11 +354,11 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
       float bv = INF, bd = INF;
       if (j != snk && dist_b[j] < INF) {
         auto consider = [&](uint32_t v) {
-          const float d = dist_b[v];
-          if (!(d < INF)) return;
-          const float val = d + weight(j, v);
-          if (best == NONE || val < bv || (val == bv && (d < bd || (d == bd && v < (uint32_t)best)))) {
-            best = (idx_t)v; bv = val; bd = d;
+          const float dv = dist_b[v];
+          if (!(dv < INF)) return;
+          const float val = dv + weight(j, v);
+          if (best == NONE || val < bv || (val == bv && (dv < bd || (dv == bd && v < (uint32_t)best)))) {
+            best = (idx_t)v; bv = val; bd = dv;
           }
         };
         if (j == src) consider(0);
@@ -298,7 +377,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     if (u == src) return 4 * m;
     if (v == snk) return 4 * m + 1;
     for (uint32_t c = 0; c < 4; ++c) if (succ[4 * u + c] == (idx_t)v) return 4 * u + c;
-    return 0xFFFFFFFFu;
+    return NIL;
   };
   auto is_removed = [&](uint32_t e) -> bool { return (removed[e >> 5] >> (e & 31)) & 1u; };
 
@@ -314,16 +393,16 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     if (__all((int)ok)) {
       for (uint32_t i = 1 + lane; i < n_ref; i += 64) {      // first edge (0 -> 1) is kept
         const uint32_t e = edge_id(i, (i + 1 < n_ref) ? i + 1 : snk);
-        if (e != 0xFFFFFFFFu) atomicOr(&removed[e >> 5], 1u << (e & 31));
+        if (e != NIL) atomicOr(&removed[e >> 5], 1u << (e & 31));
       }
     } else {
       if (lane == 0) {
-        uint32_t cur = 0, last = 0xFFFFFFFFu, hops = 0;
+        uint32_t cur = 0, last = NIL, hops = 0;
         while (after[cur] != NONE && hops++ <= n) {
           cur = after[cur];
-          if (last != 0xFFFFFFFFu && last != 0) {              // `if last_cur and ...`
+          if (last != NIL && last != 0) {                      // `if last_cur and ...`
             const uint32_t e = edge_id(last, cur);
-            if (e != 0xFFFFFFFFu) removed[e >> 5] |= 1u << (e & 31);
+            if (e != NIL) removed[e >> 5] |= 1u << (e & 31);
           }
           last = cur;
         }
@@ -334,71 +413,112 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
 
   // ---- 6. candidate edges and their unique representatives --------------------------
   const uint32_t n_edges = 4 * m + 2;
-  bool overflow = false;
-  for (uint32_t e0 = 0; e0 < n_edges; e0 += 64) {
-    const uint32_t e = e0 + lane;
-    bool keep = false;
-    uint32_t ea = 0, eb = 0;
-    if (e < n_edges) {
-      bool exists;
-      if (e == 4 * m) { ea = src; eb = 0; exists = true; }
-      else if (e == 4 * m + 1) { ea = n_ref - 1; eb = snk; exists = true; }
-      else { ea = e >> 2; const idx_t v = succ[e]; exists = (v != NONE); eb = v; }
-      if (exists && !is_removed(e) && dist_f[ea] < INF && dist_b[eb] < INF) {
-        // representative iff no candidate edge sits at an earlier generating position
-        uint32_t x = ea, y = eb, hops = 0;
-        keep = true;
-        while (hops++ <= n) {
-          if (after[x] != (idx_t)y) break;        // edge not on the sink tree: stop
-          if (x == src) break;                    // position 0
-          const uint32_t p = before[x];
-          const uint32_t pe = edge_id(p, x);
-          if (pe != 0xFFFFFFFFu && !is_removed(pe)) { keep = false; break; }
-          y = x; x = p;
-        }
-      }
+  for (uint32_t e = lane; e < n_edges; e += 64) {
+    uint32_t ea, eb;
+    bool exists;
+    if (e == 4 * m) { ea = src; eb = 0; exists = true; }
+    else if (e == 4 * m + 1) { ea = n_ref - 1; eb = snk; exists = true; }
+    else { ea = e >> 2; const idx_t v = succ[e]; exists = (v != NONE); eb = v; }
+    if (!exists || is_removed(e) || !(dist_f[ea] < INF) || !(dist_b[eb] < INF)) continue;
+    // representative iff no candidate edge sits at an earlier generating position
+    uint32_t x = ea, y = eb, hops = 0;
+    bool keep = true;
+    while (hops++ <= n) {
+      if (after[x] != (idx_t)y) break;        // edge not on the sink tree: stop
+      if (x == src) break;                    // position 0
+      const uint32_t p = before[x];
+      const uint32_t pe = edge_id(p, x);
+      if (pe != NIL && !is_removed(pe)) { keep = false; break; }
+      y = x; x = p;
     }
-    const unsigned long long km = __ballot(keep);
-    const uint32_t basec = scal[0];
     if (keep) {
-      const uint32_t slot = basec + (uint32_t)__popcll(km & ((1ull << lane) - 1));
+      const uint32_t slot = atomicAdd(&scal[0], 1u);
       if (slot < ccap) { cand[2 * slot] = (idx_t)ea; cand[2 * slot + 1] = (idx_t)eb; }
-      else overflow = true;
     }
-    __syncthreads();
-    if (lane == 0) scal[0] = basec + (uint32_t)__popcll(km);
-    __syncthreads();
   }
+  __syncthreads();
   const uint32_t n_cand = scal[0];
-  if (__any((int)overflow) || n_cand > ccap) {
+  if (n_cand > ccap) {
     if (lane == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
 
   // ---- 7. emit paths (caps stripped) as runs of consecutive node indices -------------
-  // pass 1: count runs / nodes / min coverage per path (one lane per path)
-  uint32_t total_runs = 0;
-  for (uint32_t p0 = 0; p0 < n_cand; p0 += 64) {
-    const uint32_t p = p0 + lane;
-    uint32_t nruns = 0;
-    if (p < n_cand) {
-      const uint32_t ea = cand[2 * p], eb = cand[2 * p + 1];
-      uint32_t prev = 0xFFFFFFFFu, hops = 0;
-      for (uint32_t x = ea; x != src && x != NONE && hops <= n; x = before[x], ++hops) {
-        if (prev == 0xFFFFFFFFu || x + 1 != prev) ++nruns;      // walking backwards: x == prev-1 extends
-        prev = x;
-      }
-      // junction a -> b continues the run iff b == a + 1
-      prev = (ea == src) ? 0xFFFFFFFFu : ea;
-      hops = 0;
-      for (uint32_t x = eb; x != snk && x != NONE && hops <= n; x = after[x], ++hops) {
-        if (prev == 0xFFFFFFFFu || prev + 1 != x) ++nruns;
-        prev = x;
+  // A path is walked chain by chain (wave-uniform): backwards from `a` along before[]
+  // — inside a chain before[j] == j-1 — then forwards from `b` along after[].  Runs
+  // that happen to be index-contiguous across a hop are merged.  `emit(start,len,idx)`
+  // receives the merged runs with their position in path order.
+  auto walk_path = [&](uint32_t ea, uint32_t eb, auto&& emit) -> uint32_t {
+    // backward part: count merged runs first (a hop is contiguous iff before[head] == head-1)
+    uint32_t nback = 0;
+    if (ea != src) {
+      uint32_t x = ea, hops = 0;
+      nback = 1;
+      while (hops++ <= n) {
+        const uint32_t s = chain_head(x);
+        const uint32_t p = before[s];
+        if (p == src || p == (uint32_t)NONE) break;
+        if (p + 1 != s) ++nback;
+        x = p;
       }
     }
-    for (int o = 32; o > 0; o >>= 1) nruns += __shfl_xor(nruns, o);
-    total_runs += nruns;
-  }
+    const bool glue = (ea != src) && (eb != snk) && (ea + 1 == eb);   // junction a -> b contiguous
+    // first forward merged run
+    uint32_t f_lo = NIL, f_hi = NIL, fx = NIL;      // fx: first node after that run
+    if (eb != snk) {
+      f_lo = eb;
+      uint32_t x = eb, hops = 0;
+      while (hops++ <= n) {
+        const uint32_t e = chain_end(x);
+        f_hi = e;
+        const uint32_t q = after[e];
+        if (q == snk || q == (uint32_t)NONE) { fx = NIL; break; }
+        if (q != e + 1) { fx = q; break; }
+        x = q;
+      }
+    }
+    // backward runs, discovered last-to-first
+    if (ea != src) {
+      uint32_t x = ea, hops = 0, idx = nback - 1;
+      uint32_t hi = glue ? f_hi : ea;
+      uint32_t lo = ea;
+      while (hops++ <= n) {
+        const uint32_t s = chain_head(x);
+        lo = s;
+        const uint32_t p = before[s];
+        if (p == src || p == (uint32_t)NONE) break;
+        if (p + 1 != s) { emit(lo, hi - lo + 1, idx); --idx; hi = p; }
+        x = p;
+      }
+      emit(lo, hi - lo + 1, idx);
+    }
+    uint32_t total = nback;
+    if (eb != snk) {
+      if (!glue) { emit(f_lo, f_hi - f_lo + 1, total); ++total; }
+      uint32_t x = fx, hops = 0;
+      while (x != NIL && hops++ <= n) {
+        const uint32_t lo = x;
+        uint32_t hi = x, nxt = NIL, h2 = 0;
+        while (h2++ <= n) {
+          const uint32_t e = chain_end(hi);
+          hi = e;
+          const uint32_t q = after[e];
+          if (q == snk || q == (uint32_t)NONE) { nxt = NIL; break; }
+          if (q != e + 1) { nxt = q; break; }
+          hi = q;
+        }
+        emit(lo, hi - lo + 1, total);
+        ++total;
+        x = nxt;
+      }
+    }
+    return total;
+  };
+
+  // pass 1: count runs per path
+  uint32_t total_runs = 0;
+  for (uint32_t p = 0; p < n_cand; ++p)
+    total_runs += walk_path(cand[2 * p], cand[2 * p + 1], [](uint32_t, uint32_t, uint32_t) {});
   unsigned long long run_base = 0, path_base = 0;
   if (lane == 0) {
     path_base = atomicAdd(&a.counters[0], (unsigned long long)n_cand);
@@ -415,84 +535,32 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
-  // pass 2: write the records
-  uint32_t run_cursor = 0;
-  for (uint32_t p0 = 0; p0 < n_cand; p0 += 64) {
-    const uint32_t p = p0 + lane;
-    uint32_t nruns = 0, plen = 0, mincov = 0xFFFFFFFFu;
-    uint32_t ea = 0, eb = 0;
-    if (p < n_cand) {
-      ea = cand[2 * p]; eb = cand[2 * p + 1];
-      uint32_t prev = 0xFFFFFFFFu, hops = 0;
-      for (uint32_t x = ea; x != src && x != NONE && hops <= n; x = before[x], ++hops) {
-        if (prev == 0xFFFFFFFFu || x + 1 != prev) ++nruns;
-        prev = x;
+  // pass 2: write runs, lengths and min coverage
+  uint64_t rcur = run_base;
+  for (uint32_t p = 0; p < n_cand; ++p) {
+    uint32_t plen = 0, mincov = 0xFFFFFFFFu;
+    const uint32_t nr = walk_path(cand[2 * p], cand[2 * p + 1],
+                                  [&](uint32_t start, uint32_t len, uint32_t idx) {
+      if (lane == 0) { a.r_start[rcur + idx] = start; a.r_len[rcur + idx] = len; }
+      plen += len;
+      for (uint32_t q = lane; q < len; q += 64) {
+        const uint32_t c = ncnt[start + q];
+        mincov = c < mincov ? c : mincov;
       }
-      prev = (ea == src) ? 0xFFFFFFFFu : ea;
-      hops = 0;
-      for (uint32_t x = eb; x != snk && x != NONE && hops <= n; x = after[x], ++hops) {
-        if (prev == 0xFFFFFFFFu || prev + 1 != x) ++nruns;
-        prev = x;
-      }
+    });
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = __shfl_xor(mincov, o);
+      mincov = other < mincov ? other : mincov;
     }
-    // exclusive prefix of nruns over lanes
-    uint32_t incl = nruns;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o);
-      if ((int)lane >= o) incl += up;
-    }
-    const uint32_t excl = incl - nruns;
-    const uint32_t chunk_total = __shfl(incl, 63);
-    if (p < n_cand) {
-      const uint64_t rb = run_base + run_cursor + excl;
-      // backward part: runs are discovered last-to-first; fill from its end
-      uint32_t nback = 0;
-      {
-        uint32_t prev = 0xFFFFFFFFu, hops = 0;
-        for (uint32_t x = ea; x != src && x != NONE && hops <= n; x = before[x], ++hops) {
-          if (prev == 0xFFFFFFFFu || x + 1 != prev) ++nback;
-          prev = x;
-        }
-      }
-      {
-        uint32_t prev = 0xFFFFFFFFu, hops = 0, ri = nback, rlen = 0;
-        for (uint32_t x = ea; x != src && x != NONE && hops <= n; x = before[x], ++hops) {
-          if (prev == 0xFFFFFFFFu || x + 1 != prev) {
-            if (prev != 0xFFFFFFFFu) { a.r_start[rb + ri] = prev; a.r_len[rb + ri] = rlen; }
-            --ri; rlen = 0;
-          }
-          ++rlen; ++plen;
-          const uint32_t c = cnt[x];
-          mincov = c < mincov ? c : mincov;
-          prev = x;
-        }
-        if (prev != 0xFFFFFFFFu) { a.r_start[rb + ri] = prev; a.r_len[rb + ri] = rlen; }
-      }
-      {
-        // forward part; the first node may extend the last backward run
-        uint32_t prev = (ea == src) ? 0xFFFFFFFFu : ea;
-        uint32_t ri = nback;          // index of the next new run
-        uint32_t hops = 0;
-        for (uint32_t x = eb; x != snk && x != NONE && hops <= n; x = after[x], ++hops) {
-          if (prev == 0xFFFFFFFFu || prev + 1 != x) {
-            a.r_start[rb + ri] = x; a.r_len[rb + ri] = 1; ++ri;
-          } else {
-            a.r_len[rb + ri - 1] += 1;
-          }
-          ++plen;
-          const uint32_t c = cnt[x];
-          mincov = c < mincov ? c : mincov;
-          prev = x;
-        }
-      }
+    if (lane == 0) {
       const uint64_t pi = path_base + p;
       a.p_target[pi] = t;
-      a.p_runbase[pi] = rb;
-      a.p_nruns[pi] = nruns;
+      a.p_runbase[pi] = rcur;
+      a.p_nruns[pi] = nr;
       a.p_len[pi] = plen;
       a.p_mincov[pi] = mincov;
     }
-    run_cursor += chunk_total;
+    rcur += nr;
   }
   if (lane == 0) {
     a.g_status[t] = T_OK;

@@ -545,6 +545,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
 static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.k = b->db->k;
   g.kmask = mask_bits(b->db->k);
+  g.pmask = mask_bits(b->db->k - 1);
   g.tids = nullptr;
   g.n_targets = b->n_targets;
   g.node_kmer = b->d_node_kmer.p;
@@ -603,7 +604,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   GraphArgs& ga = b->ga;
   fill_graph_args(b, ga);
   ga.ncap = max_nref + FAST_EXTRA + 2;
-  ga.hcap = round_up(2 * ga.ncap, 64);
+  ga.hcap = round_up(ga.ncap + ga.ncap / 2 + 1, 64);
   const uint64_t gl = graph_ws_bytes<uint16_t>(ga.ncap, ga.hcap);
   b->fast_ok = wl <= FAST_LDS_LIMIT && gl <= FAST_LDS_LIMIT && ga.ncap < 0xFFFF &&
                b->p.max_break < 4096;
@@ -729,7 +730,7 @@ static int run_big_graph(km_batch* b, const std::vector<uint32_t>& ids, hipStrea
   GraphArgs g;
   fill_graph_args(b, g);
   g.ncap = max_nodes + 2;
-  g.hcap = round_up(2 * g.ncap, 64);
+  g.hcap = round_up(g.ncap + g.ncap / 2 + 1, 64);
   g.g_stride = graph_ws_bytes<uint32_t>(g.ncap, g.hcap);
   const uint64_t budget = 8ull << 30;
   uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb, budget / g.g_stride));
@@ -761,7 +762,7 @@ static int relaunch_fast_graph(km_batch* b, hipStream_t st) {
   fill_graph_args(b, b->ga);
   const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
   b->ga.ncap = max_nref + FAST_EXTRA + 2;
-  b->ga.hcap = round_up(2 * b->ga.ncap, 64);
+  b->ga.hcap = round_up(b->ga.ncap + b->ga.ncap / 2 + 1, 64);
   int rc = launch_graph_fast(b, st);
   if (rc != KM_OK) return rc;
   HIPCHK(hipStreamSynchronize(st));
