@@ -55,7 +55,7 @@ struct GraphArgs {
   const uint64_t* node_base;
   const uint32_t* n_nodes;
   const uint32_t* n_ref;
-  const uint32_t* status;
+  uint32_t* status;          // T_REPEAT is raised here (duplicate k-mer in the target)
   // outputs
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
@@ -72,6 +72,7 @@ struct GraphArgs {
   // geometry
   uint32_t ncap;   // max nodes incl. caps
   uint32_t hcap;   // prefix-table slots, multiple of 64, >= 1.5 * ncap
+  uint32_t dbg;    // diagnostic (KM_DEBUG_FLAGS >> 8): stop after step N (timing ablation only)
   unsigned char* g_ws;
   uint64_t g_stride;
 };
@@ -167,6 +168,29 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     if (s >= 0) pidx[4 * s + (uint32_t)(X & 3)] = (idx_t)j;
   }
   __syncthreads();
+  // a k-mer present twice (km/utils/common.py:55-59) shares one table entry: one of the
+  // two nodes does not find its own index there
+  {
+    uint32_t dup = 0;
+    for (uint32_t j = lane; j < m; j += 64) {
+      const uint64_t X = nk[j];
+      const uint64_t P = X >> 2;
+      uint32_t s = set_home(P, hcap);
+      idx_t got = NONE;
+      for (uint32_t step = 0; step < hcap; ++step) {
+        const uint64_t kv = pkeys[s];
+        if (kv == P) { got = pidx[4 * s + (uint32_t)(X & 3)]; break; }
+        if (kv == EMPTY) break;
+        if (++s == hcap) s = 0;
+      }
+      if (got != (idx_t)j) dup = 1;
+    }
+    if (__any((int)dup)) {
+      if (lane == 0) { a.status[t] = T_REPEAT; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+      return;
+    }
+  }
+  if (a.dbg == 1) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 2. adjacency: succ[4j+c] = node of kmer[j][1:]+c ; pred[4v+f] = j, f = first base of j
   for (uint32_t j = lane; j < m; j += 64) {
     const uint64_t X = nk[j];
@@ -190,6 +214,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     }
   }
   __syncthreads();
+  if (a.dbg == 2) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 2b. link[j]: j -> j+1 is j's only out-edge and j+1's only in-edge ---------------
   for (uint32_t base = 0; base < m; base += 64) {
     const uint32_t j = base + lane;
@@ -233,6 +258,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     return s;
   };
 
+  if (a.dbg == 3) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 3. exact distances -------------------------------------------------------------
   for (int dir = 0; dir < 2; ++dir) {
     float* dist = dir ? dist_b : dist_f;
@@ -327,6 +353,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     }
   }
 
+  if (a.dbg == 4) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 4. predecessor arrays by the local rule ------------------------------------
   for (uint32_t j = lane; j < n; j += 64) {
     {
@@ -381,6 +408,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   };
   auto is_removed = [&](uint32_t e) -> bool { return (removed[e >> 5] >> (e & 31)) & 1u; };
 
+  if (a.dbg == 5) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 5. strip reference edges (Graph.py:184-197) ---------------------------------
   // curs = nodes whose predecessor is the source; only node 0 has an edge from it.
   if (before[0] == (idx_t)src) {
@@ -411,6 +439,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   }
   __syncthreads();
 
+  if (a.dbg == 6) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 6. candidate edges and their unique representatives --------------------------
   const uint32_t n_edges = 4 * m + 2;
   for (uint32_t e = lane; e < n_edges; e += 64) {
@@ -443,6 +472,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     return;
   }
 
+  if (a.dbg == 7) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 7. emit paths (caps stripped) as runs of consecutive node indices -------------
   // A path is walked chain by chain (wave-uniform): backwards from `a` along before[]
   // — inside a chain before[j] == j-1 — then forwards from `b` along after[].  Runs

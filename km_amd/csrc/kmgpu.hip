@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -187,7 +188,10 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   HIPCHK(hipSetDevice(device));
   // every record enters at most two groups; keep the load factor <= 0.5
   uint64_t entries = (h->canonical ? 2 : 1) * n;
-  uint64_t n_slots = std::max<uint64_t>(1024, entries * 2);
+  // KM_TABLE_LOAD: target load factor of the HBM table (default 0.5; HBM is plentiful)
+  double load = 0.5;
+  if (const char* lf = getenv("KM_TABLE_LOAD")) { double v = atof(lf); if (v >= 0.05 && v <= 0.9) load = v; }
+  uint64_t n_slots = std::max<uint64_t>(1024, (uint64_t)((double)entries / load) + 1);
   n_slots = (n_slots + 63) & ~63ull;
   Slot* slots = nullptr;
   HIPCHK(hipMalloc((void**)&slots, n_slots * sizeof(Slot)));
@@ -353,6 +357,16 @@ struct km_batch {
   DevBuf<uint8_t> d_bases;
   DevBuf<uint64_t> d_toff;
   std::vector<uint64_t> h_toff;
+  DevBuf<uint64_t> d_woff, d_packed;   // 2-bit packed targets (k_pack)
+  std::vector<uint64_t> h_woff;
+  // k_seed work items and flag bitmaps
+  DevBuf<uint32_t> d_item_t, d_item_start, d_flagbits, d_tflag, d_flagged, d_nflagged;
+  DevBuf<uint64_t> d_fw_off;
+  std::vector<uint32_t> h_item_t, h_item_start;
+  std::vector<uint64_t> h_fw_off;
+  uint32_t n_items = 0;
+  bool big_walk_done = false;
+  int graph_mode = 0;                  // 1 = duplicate check only (walk stage run alone)
   // per-target
   DevBuf<uint64_t> d_node_base;
   DevBuf<uint32_t> d_node_cap;
@@ -403,6 +417,15 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   auto A = [&](int r) { if (rc == KM_OK) rc = r; };
   A(b->d_bases.alloc(max_total_bases + 64));
   A(b->d_toff.alloc((uint64_t)max_targets + 1));
+  A(b->d_woff.alloc((uint64_t)max_targets + 1));
+  A(b->d_packed.alloc(max_total_bases / 32 + 2 * (uint64_t)max_targets + 2));
+  A(b->d_item_t.alloc(max_total_bases / SEED_BLOCK + (uint64_t)max_targets + 1));
+  A(b->d_item_start.alloc(max_total_bases / SEED_BLOCK + (uint64_t)max_targets + 1));
+  A(b->d_flagbits.alloc(max_total_bases / 32 + (uint64_t)max_targets + 1));
+  A(b->d_fw_off.alloc((uint64_t)max_targets + 1));
+  A(b->d_tflag.alloc(max_targets));
+  A(b->d_flagged.alloc(max_targets));
+  A(b->d_nflagged.alloc(1));
   A(b->d_node_base.alloc(max_targets));
   A(b->d_node_cap.alloc(max_targets));
   A(b->d_n_nodes.alloc(max_targets));
@@ -439,7 +462,9 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   if (!b) return KM_OK;
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
-  b->d_bases.release(); b->d_toff.release(); b->d_node_base.release(); b->d_node_cap.release();
+  b->d_bases.release(); b->d_toff.release(); b->d_woff.release(); b->d_packed.release();
+  b->d_item_t.release(); b->d_item_start.release(); b->d_flagbits.release(); b->d_fw_off.release();
+  b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
   b->d_npaths.release(); b->d_pathbase.release(); b->d_probes.release(); b->d_fetches.release();
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
@@ -460,6 +485,10 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
   if (total > b->max_bases) return fail(KM_E_ARG, "too many bases for this batch");
   const int k = b->db->k;
   b->h_toff.assign(n + 1, 0);
+  b->h_woff.assign(n + 1, 0);
+  b->h_fw_off.assign(n + 1, 0);
+  b->h_item_t.clear();
+  b->h_item_start.clear();
   b->h_node_base.assign(n, 0);
   b->h_node_cap.assign(n, 0);
   uint64_t pool = 0;
@@ -469,7 +498,10 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
     const uint64_t L = offsets[t + 1] - offsets[t];
     if (L > 0x7FFFFFFFull) return fail(KM_E_ARG, "target too long");
     b->h_toff[t] = offsets[t] - offsets[0];
+    b->h_woff[t + 1] = b->h_woff[t] + (L + 31) / 32 + 1;
     const uint32_t n_ref = (L >= (uint64_t)k) ? (uint32_t)(L - k + 1) : 0;
+    b->h_fw_off[t + 1] = b->h_fw_off[t] + (n_ref + 31) / 32;
+    for (uint32_t st0 = 0; st0 < n_ref; st0 += SEED_BLOCK) { b->h_item_t.push_back(t); b->h_item_start.push_back(st0); }
     b->h_node_base[t] = pool;
     b->h_node_cap[t] = n_ref + FAST_EXTRA;
     pool += (uint64_t)n_ref + FAST_EXTRA;
@@ -477,6 +509,7 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
   }
   b->h_toff[n] = total;
   b->node_pool_used = pool;
+  b->n_items = (uint32_t)b->h_item_t.size();
   b->n_targets = n;
   b->total_bases = total;
   b->max_len = max_len;
@@ -486,6 +519,12 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
 static int push_layout(km_batch* b, hipStream_t st) {
   const uint32_t n = b->n_targets;
   HIPCHK(hipMemcpyAsync(b->d_toff.p, b->h_toff.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_woff.p, b->h_woff.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_fw_off.p, b->h_fw_off.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+  if (b->n_items) {
+    HIPCHK(hipMemcpyAsync(b->d_item_t.p, b->h_item_t.data(), (uint64_t)b->n_items * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_item_start.p, b->h_item_start.data(), (uint64_t)b->n_items * 4, hipMemcpyHostToDevice, st));
+  }
   HIPCHK(hipMemcpyAsync(b->d_node_base.p, b->h_node_base.data(), (uint64_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_node_cap.p, b->h_node_cap.data(), (uint64_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -519,16 +558,29 @@ extern "C" int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases,
 }
 
 static void fill_walk_args(km_batch* b, WalkArgs& a) {
+  memset(&a, 0, sizeof a);
   a.tab = view_of(b->db);
   a.bases = b->d_bases.p;
   a.toff = b->d_toff.p;
-  a.tids = nullptr;
+  a.packed = b->d_packed.p;
+  a.woff = b->d_woff.p;
   a.n_targets = b->n_targets;
   a.ratio = b->p.ratio;
   a.n_cutoff = b->p.count;
   a.max_stack = b->p.max_stack;
   a.max_break = b->p.max_break;
   a.max_node = b->p.max_node;
+  a.item_t = b->d_item_t.p;
+  a.item_start = b->d_item_start.p;
+  a.n_items = b->n_items;
+  a.flagbits = b->d_flagbits.p;
+  a.fw_off = b->d_fw_off.p;
+  a.tflag = b->d_tflag.p;
+  a.flagged = b->d_flagged.p;
+  a.n_flagged = b->d_nflagged.p;
+  a.list = b->d_flagged.p;
+  a.n_list_dev = b->d_nflagged.p;
+  a.n_list_host = 0;
   a.node_kmer = b->d_node_kmer.p;
   a.node_cnt = b->d_node_cnt.p;
   a.node_base = b->d_node_base.p;
@@ -536,10 +588,12 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.n_nodes = b->d_n_nodes.p;
   a.n_ref = b->d_n_ref.p;
   a.status = b->d_status.p;
-  a.probes = b->d_probes.p;
-  a.fetches = b->d_fetches.p;
+  a.probes = reinterpret_cast<unsigned long long*>(b->d_probes.p);
+  a.fetches = reinterpret_cast<unsigned long long*>(b->d_fetches.p);
   a.g_ws = nullptr;
   a.g_stride = 0;
+  const char* dbg = getenv("KM_DEBUG_FLAGS");   // timing ablations only; results are invalid
+  a.dbg = dbg ? ((uint32_t)strtoul(dbg, nullptr, 0) & 0xFFu) : 0;
 }
 
 static void fill_graph_args(km_batch* b, GraphArgs& g) {
@@ -569,6 +623,9 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.r_len = b->d_r_len.p;
   g.g_ws = nullptr;
   g.g_stride = 0;
+  const char* dbg = getenv("KM_DEBUG_FLAGS");
+  g.dbg = dbg ? ((uint32_t)strtoul(dbg, nullptr, 0) >> 8) : 0;
+  if (b->graph_mode == 1) g.dbg = 1;       // duplicate check only
 }
 
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
@@ -599,8 +656,8 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   wa.words_cap = round_up((b->max_len + 31) / 32 + 1, 2);
   wa.fcap = round_up(b->p.max_stack + 2, 2);
   wa.bcap = b->p.max_break + 1;
-  wa.flag_words = round_up((max_nref + 31) / 32, 2);
-  const uint64_t wl = walk_ws_bytes(wa.hs_cap, wa.words_cap, wa.fcap, wa.bcap, wa.flag_words);
+  const uint64_t wl = walk_ws_bytes(wa.hs_cap, wa.words_cap, wa.fcap, wa.bcap);
+  b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
   GraphArgs& ga = b->ga;
   fill_graph_args(b, ga);
   ga.ncap = max_nref + FAST_EXTRA + 2;
@@ -613,29 +670,29 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
 
   if (stages & KM_STAGE_WALK) {
     HIPCHK(hipEventRecord(b->ev[0], st));
-    if (b->fast_ok) {
-      hipLaunchKernelGGL(k_walk<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
-      HIPCHK(hipGetLastError());
-    } else {
-      // everything goes to the large tier at sync time
-      std::vector<uint32_t> need(b->n_targets, T_NEEDS_BIG);
-      HIPCHK(hipMemcpyAsync(b->d_status.p, need.data(), (uint64_t)b->n_targets * 4, hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));
-    }
+    hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
+    if (b->n_items)
+      hipLaunchKernelGGL(k_seed, dim3(b->n_items), dim3(SEED_BLOCK), 0, st, wa);
+    if (b->fast_ok)
+      hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev[1], st));
     b->ran_walk = true;
     b->ran_graph = false;
+    b->big_walk_done = false;
   } else if (!b->ran_walk) {
     return fail(KM_E_STATE, "graph stage requested before the walk stage");
   } else {
     HIPCHK(hipEventRecord(b->ev[0], st));
     HIPCHK(hipEventRecord(b->ev[1], st));
   }
-  if (stages & KM_STAGE_GRAPH) {
+  // the graph kernel also hosts the duplicate-k-mer check, so it always runs
+  // (graph_mode 1 = stop after that check)
+  {
     int rc = launch_graph_fast(b, st);
     if (rc != KM_OK) return rc;
-    b->ran_graph = true;
   }
+  b->ran_graph = true;                      // graph_mode says how far it went
   HIPCHK(hipEventRecord(b->ev[2], st));
   b->synced = false;
   return KM_OK;
@@ -666,6 +723,8 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   const int k = b->db->k;
   // per-target node storage big enough for the reference's own bound
   uint64_t extra = 0;
+  std::vector<uint64_t> old_base;
+  for (uint32_t t : ids) old_base.push_back(b->h_node_base[t]);
   for (uint32_t t : ids) {
     const uint64_t L = b->h_toff[t + 1] - b->h_toff[t];
     const uint32_t n_ref = (L >= (uint64_t)k) ? (uint32_t)(L - k + 1) : 0;
@@ -688,6 +747,16 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
     b->d_node_kmer = nk; b->d_node_cnt = nc;
   }
   b->node_pool_used = need;
+  // the seed kernel's results (target k-mers and their counts) move to the new storage
+  for (size_t q = 0; q < ids.size(); ++q) {
+    const uint32_t t = ids[q];
+    const uint64_t nref = b->h_n_ref[t];
+    if (!nref) continue;
+    HIPCHK(hipMemcpyAsync(b->d_node_kmer.p + b->h_node_base[t], b->d_node_kmer.p + old_base[q], nref * 8,
+                          hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_node_cnt.p + b->h_node_base[t], b->d_node_cnt.p + old_base[q], nref * 4,
+                          hipMemcpyDeviceToDevice, st));
+  }
   HIPCHK(hipMemcpyAsync(b->d_node_base.p, b->h_node_base.data(), (uint64_t)b->n_targets * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_node_cap.p, b->h_node_cap.data(), (uint64_t)b->n_targets * 4, hipMemcpyHostToDevice, st));
   int rc = b->d_big_ids.alloc(nb); if (rc != KM_OK) return rc;
@@ -696,7 +765,7 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   const uint32_t max_nref = b->max_len >= (uint32_t)k ? b->max_len - k + 1 : 1;
   WalkArgs a;
   fill_walk_args(b, a);
-  a.tids = b->d_big_ids.p;
+  a.n_list_dev = nullptr;
   const uint64_t max_nodes = std::max<uint64_t>(max_nref, (uint64_t)b->p.max_node + b->p.max_stack) + 1;
   const uint64_t hs = 2 * (max_nodes + b->p.max_stack + 64);
   if (hs > 0x7FFFFF00ull) return fail(KM_E_ARG, "node limit too large");
@@ -704,8 +773,7 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   a.words_cap = round_up((b->max_len + 31) / 32 + 1, 2);
   a.fcap = round_up(b->p.max_stack + 2, 2);
   a.bcap = b->p.max_break + 1;
-  a.flag_words = round_up((max_nref + 31) / 32, 2);
-  a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap, a.flag_words);
+  a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap);
   // run in slices so the workspace stays bounded
   const uint64_t budget = 8ull << 30;
   uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb, budget / a.g_stride));
@@ -713,8 +781,9 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   a.g_ws = b->d_big_ws.p;
   for (uint32_t s = 0; s < nb; s += per) {
     const uint32_t cnt = std::min(per, nb - s);
-    a.tids = b->d_big_ids.p + s;
-    hipLaunchKernelGGL(k_walk<true>, dim3(cnt), dim3(64), 0, st, a);
+    a.list = b->d_big_ids.p + s;
+    a.n_list_host = cnt;
+    hipLaunchKernelGGL(k_dfs<true>, dim3(cnt), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -786,7 +855,18 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   const uint32_t n = b->n_targets;
 
   std::vector<uint32_t> big;
-  for (uint32_t t = 0; t < n; ++t) if (b->h_status[t] == T_NEEDS_BIG) big.push_back(t);
+  if (b->fast_ok) {
+    for (uint32_t t = 0; t < n; ++t) if (b->h_status[t] == T_NEEDS_BIG) big.push_back(t);
+  } else if (!b->big_walk_done) {
+    // no LDS-resident tier for these parameters: every flagged target takes the large tier
+    uint32_t nf = 0;
+    HIPCHK(hipMemcpy(&nf, b->d_nflagged.p, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> fl(nf);
+    if (nf) HIPCHK(hipMemcpy(fl.data(), b->d_flagged.p, (uint64_t)nf * 4, hipMemcpyDeviceToHost));
+    for (uint32_t t : fl) if (b->h_status[t] == T_OK) big.push_back(t);
+    std::sort(big.begin(), big.end());
+  }
+  b->big_walk_done = true;
   b->n_big = (uint32_t)big.size();
   std::vector<char> force_big(n, 0);
   if (!big.empty()) {

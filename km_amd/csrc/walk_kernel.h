@@ -4,33 +4,40 @@
 // extend from each) and :137-165 (recursive DFS with budgets), calling
 // Jellyfish.get_child / query (km/utils/Jellyfish.py:47-72).
 //
-// One 64-lane workgroup (= one wavefront) per target.
+// Three kernels:
 //
-//  Phase A (lane-parallel, the bulk of all probes).  Lane j handles target
-//  k-mers j, j+64, ...: it inserts the k-mer into the per-target node set (LDS,
-//  open addressing; a duplicate raises the reference's ValueError), fetches ONE
-//  32-byte sibling bucket from HBM (device_common.h) which yields the four child
-//  counts of get_child AND the count of the next target k-mer, thresholds the
-//  children and classifies the seed: "trivial" when it has no child or its only
-//  child is the next target k-mer (then __extend registers nothing new), else it
-//  is flagged in an LDS bitmap.  Trivial seeds cannot change node_data, so
-//  handling them out of order is exact.
+//  k_pack  (one wave per target)  ASCII -> 2-bit words, per-target initial status
+//          (empty / bad base / node limit already hit by the target itself).
 //
-//  Phase B (wave-uniform).  Flagged seeds are walked one after the other in
-//  target order with the reference's exact DFS semantics (child order ACGT,
-//  len(stack) > max_stack, breaks > max_break, node limit checked at every
-//  extension call, registration of the whole stack on a rejoin or a loop).  All
-//  64 lanes cooperate on each step: set membership is one LDS window read +
-//  ballot, stack registration and un-marking are lane-strided.  Only frames that
-//  still have untried children are kept as "branch frames" (at most max_break of
-//  them), so unwinding jumps straight to the next untried child.
+//  k_seed  (one THREAD per target k-mer, flat over the whole batch, no per-target
+//          LDS state, full occupancy — the HBM-bound part and ~85 % of all logical
+//          probes).  Thread (t, i) fetches ONE 32-byte sibling bucket
+//          (device_common.h) which yields the four child counts of
+//          get_child(ref[i]) AND the count of ref[i+1], thresholds the children
+//          and classifies the seed: "trivial" when it has no child or its only
+//          child is the next target k-mer (then __extend registers nothing new),
+//          else its bit is set in the target's flag bitmap and the target joins
+//          the flagged list.  Trivial seeds cannot change node_data, so handling
+//          them out of order is exact.
+//
+//  k_dfs   (one wave per FLAGGED target)  builds the target's node set in LDS
+//          and walks the flagged seeds one after the other in target order with
+//          the reference's exact DFS semantics (child order ACGT, len(stack) >
+//          max_stack, breaks > max_break, node limit checked at every extension
+//          call, registration of the whole stack on a rejoin or a loop).  All 64
+//          lanes cooperate on each step: set membership is one LDS window read +
+//          ballot, stack registration and un-marking are lane-strided.  Only
+//          frames that still have untried children are kept as "branch frames"
+//          (at most max_break of them), so unwinding jumps straight to the next
+//          untried child.  BIG=true keeps the per-target state in a global
+//          workspace for the few targets that outgrow the LDS budget.
+//
+// A k-mer occurring twice in a target (the reference's ValueError,
+// km/utils/common.py:55-59) is detected where a hash of the target's k-mers is
+// built anyway: in k_dfs for flagged targets and in the graph kernel for all.
 //
 // Node order written out (canonical order): target k-mers in target
 // order, then registered k-mers in registration (stack) order.
-//
-// The same code is instantiated twice: BIG=false keeps all per-target state in
-// LDS (fast tier); BIG=true keeps it in a global workspace and is used for the
-// few targets whose node set / stack outgrow the LDS budget.
 #pragma once
 #include "device_common.h"
 
@@ -40,21 +47,38 @@ constexpr uint32_t ST_NODE = 1, ST_ONSTACK = 2, ST_POPPED = 3;
 constexpr uint32_t T_OK = 0, T_NODE_LIMIT = 1, T_REPEAT = 2, T_EMPTY = 3, T_BAD_BASE = 4,
                    T_INTERNAL = 5, T_NEEDS_BIG = 100;
 constexpr uint64_t DFS_STEP_LIMIT = 1ull << 32;
+constexpr uint32_t SEED_BLOCK = 256;     // seeds per k_seed work item
 
 struct __attribute__((aligned(16))) BranchFrame {
   uint4 c4;
   uint32_t depth, mask, brk, pad;
 };
 
+// Everything the three kernels share.
 struct WalkArgs {
   TableView tab;
-  const uint8_t* bases;
-  const uint64_t* toff;
-  const uint32_t* tids;       // BIG: target ids to (re)run; nullptr = blockIdx.x
+  const uint8_t* bases;       // ASCII input (k_pack only)
+  const uint64_t* toff;       // base offsets (target lengths)
+  uint64_t* packed;           // 2-bit packed targets
+  const uint64_t* woff;       // word offsets into `packed`
   uint32_t n_targets;
   double ratio;
   int64_t n_cutoff;
   uint32_t max_stack, max_break, max_node;
+  // k_seed work items: (target, first seed)
+  const uint32_t* item_t;
+  const uint32_t* item_start;
+  uint32_t n_items;
+  // flagged seeds / targets
+  uint32_t* flagbits;         // per target bitmap, words at fw_off[t]
+  const uint64_t* fw_off;
+  uint32_t* tflag;            // per target: already in the flagged list
+  uint32_t* flagged;          // list of flagged targets (any order)
+  uint32_t* n_flagged;        // device counter
+  // k_dfs target selection: list + count (device counter or host value)
+  const uint32_t* list;
+  const uint32_t* n_list_dev;
+  uint32_t n_list_host;
   // per-target outputs
   uint64_t* node_kmer;
   uint32_t* node_cnt;
@@ -63,21 +87,20 @@ struct WalkArgs {
   uint32_t* n_nodes;
   uint32_t* n_ref;
   uint32_t* status;
-  uint64_t* probes;
-  uint64_t* fetches;
-  // workspace geometry (LDS for the fast tier, per-block global for BIG)
+  unsigned long long* probes;
+  unsigned long long* fetches;
+  // k_dfs workspace geometry (LDS for the fast tier, per-block global for BIG)
   uint32_t hs_cap;      // node-set slots, multiple of 64
   uint32_t words_cap;   // packed-target words (even)
   uint32_t fcap;        // stack frames (even) >= max_stack + 2
   uint32_t bcap;        // branch frames >= max_break + 1
-  uint32_t flag_words;  // bitmap words
+  uint32_t dbg;         // diagnostic ablation flags (KM_DEBUG_FLAGS): 1 = skip k_dfs work
   unsigned char* g_ws;  // BIG only
   uint64_t g_stride;    // BIG only: bytes per block
 };
 
 __host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t words_cap,
-                                                  uint32_t fcap, uint32_t bcap,
-                                                  uint32_t flag_words) {
+                                                  uint32_t fcap, uint32_t bcap) {
   uint64_t b = 0;
   b += (uint64_t)hs_cap * 8;       // keys
   b += (uint64_t)words_cap * 8;    // packed target
@@ -85,8 +108,6 @@ __host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t word
   b += (uint64_t)bcap * 32;        // branch frames
   b += (uint64_t)fcap * 4;         // frame counts
   b += (uint64_t)fcap * 4;         // frame set slots
-  b += (uint64_t)((flag_words + 1) & ~1u) * 4;   // flagged-seed bitmap (kept 8-byte aligned)
-  b += 16;                         // accumulators
   b += (uint64_t)hs_cap;           // slot states
   return (b + 15) & ~15ull;
 }
@@ -136,11 +157,124 @@ __device__ inline int set_find(const uint64_t* keys, uint32_t cap, uint64_t key,
   return -1;
 }
 
+// ---------------------------------------------------------------------------- k_pack
+// ASCII bases -> 2-bit words (32 bases per uint64_t, first base most significant),
+// one extra zero word per target; per-target initial state.
+__global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
+  const uint32_t t = blockIdx.x;
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint64_t off = a.toff[t];
+  const uint64_t L = a.toff[t + 1] - off;
+  const uint64_t wo = a.woff[t];
+  const uint32_t nwords = (uint32_t)((L + 31) >> 5);
+  const uint32_t n_ref = (L >= (uint64_t)a.tab.k) ? (uint32_t)(L - a.tab.k + 1) : 0;
+  uint32_t bad = 0;
+  for (uint32_t w = lane; w <= nwords; w += 64) {
+    uint64_t v = 0;
+    if (w < nwords) {
+      const uint64_t p0 = (uint64_t)w << 5;
+#pragma unroll 8
+      for (uint32_t j = 0; j < 32; ++j) {
+        uint32_t code = 0;
+        if (p0 + j < L) {
+          const uint32_t ch = a.bases[off + p0 + j] & 0xDFu;   // upper-case
+          bad |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
+          code = ((ch >> 1) ^ (ch >> 2)) & 3u;
+        }
+        v = (v << 2) | code;
+      }
+    }
+    a.packed[wo + w] = v;
+  }
+  const uint64_t fwo = a.fw_off[t];
+  for (uint32_t w = lane; w < (n_ref + 31) / 32; w += 64) a.flagbits[fwo + w] = 0;
+  const int any_bad = __any((int)bad);
+  if (lane == 0) {
+    uint32_t st = T_OK;
+    if (n_ref == 0) st = T_EMPTY;
+    else if (any_bad) st = T_BAD_BASE;
+    else if (a.max_stack > 0 && n_ref > a.max_node) st = T_NODE_LIMIT;  // first __extend call exits
+    a.status[t] = st;
+    a.n_ref[t] = n_ref;
+    a.n_nodes[t] = (st == T_OK || st == T_NODE_LIMIT) ? n_ref : 0;
+    a.probes[t] = 0;
+    a.fetches[t] = 0;
+    a.tflag[t] = 0;
+    if (t == 0) *a.n_flagged = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------- k_seed
+__global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
+  __shared__ uint64_t words[SEED_BLOCK / 32 + 4];
+  const uint32_t item = blockIdx.x;
+  const uint32_t t = a.item_t[item];
+  if (a.status[t] != T_OK) return;
+  const TableView tab = a.tab;
+  const int k = tab.k;
+  const uint32_t start = a.item_start[item];
+  const uint32_t n_ref = a.n_ref[t];
+  const uint32_t i = start + threadIdx.x;
+  const uint64_t wo = a.woff[t];
+  // this block needs bases [start, start + SEED_BLOCK + k): at most SEED_BLOCK/32 + 3 words
+  const uint32_t w0 = start >> 5;
+  if (threadIdx.x < SEED_BLOCK / 32 + 4) {
+    const uint64_t L = a.toff[t + 1] - a.toff[t];
+    const uint32_t nwords = (uint32_t)((L + 31) >> 5);
+    const uint32_t w = w0 + threadIdx.x;
+    words[threadIdx.x] = (w <= nwords) ? a.packed[wo + w] : 0ull;
+  }
+  __syncthreads();
+  unsigned long long probes_l = 0;
+  uint32_t fetch_l = 0;
+  if (i < n_ref) {
+    const uint64_t nb = a.node_base[t];
+    const uint32_t w = (i >> 5) - w0, sh = (i & 31) * 2;
+    const uint64_t hi = words[w], lo = words[w + 1];
+    const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+    const uint64_t X = x >> (64 - 2 * k);
+    a.node_kmer[nb + i] = X;
+    const uint4 c4 = forward_children(tab, X, &fetch_l);
+    uint32_t nextb = 4;
+    if (i + 1 < n_ref) {
+      const uint32_t p = i + (uint32_t)k;                 // last base of ref[i+1]
+      nextb = (uint32_t)(words[(p >> 5) - w0] >> (62 - 2 * (p & 31))) & 3u;
+      a.node_cnt[nb + i + 1] = pick4(c4, nextb);
+    }
+    if (i == 0) a.node_cnt[nb] = query_one(tab, X, &fetch_l);
+    probes_l = 1;                                          // node_data[s] = jf.query(s)
+    if (a.max_stack > 0) {
+      const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
+      const bool trivial = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
+      if (trivial) {
+        probes_l += 4 + (mask ? 1 : 0);                    // get_child + re-query of [seed]
+      } else {
+        atomicOr(&a.flagbits[a.fw_off[t] + (i >> 5)], 1u << (i & 31));
+        if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
+      }
+    }
+  }
+  // one atomic per wave for the per-target counters
+  unsigned long long f64 = fetch_l;
+  for (int o = 32; o > 0; o >>= 1) {
+    probes_l += __shfl_xor(probes_l, o);
+    f64 += __shfl_xor(f64, o);
+  }
+  if ((threadIdx.x & 63) == 0 && probes_l) {
+    atomicAdd(&a.probes[t], probes_l);
+    atomicAdd(&a.fetches[t], f64);
+  }
+}
+
+// ---------------------------------------------------------------------------- k_dfs
 template <bool BIG>
-__global__ __launch_bounds__(64) void k_walk(WalkArgs a) {
+__global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t lane = (uint32_t)lane_id();
-  const uint32_t t = a.tids ? a.tids[blockIdx.x] : blockIdx.x;
+  const uint32_t n_list = a.n_list_dev ? *a.n_list_dev : a.n_list_host;
+  if (blockIdx.x >= n_list) return;
+  const uint32_t t = a.list[blockIdx.x];
+  if (a.status[t] != T_OK && a.status[t] != T_NEEDS_BIG) return;
   const TableView tab = a.tab;
   const int k = tab.k;
 
@@ -154,113 +288,51 @@ __global__ __launch_bounds__(64) void k_walk(WalkArgs a) {
   BranchFrame* bf = reinterpret_cast<BranchFrame*>(fk + a.fcap);
   uint32_t* fc = reinterpret_cast<uint32_t*>(bf + a.bcap);
   uint32_t* fs = fc + a.fcap;
-  uint32_t* flag = fs + a.fcap;
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(flag + a.flag_words + (a.flag_words & 1));
-  uint8_t* state = reinterpret_cast<uint8_t*>(acc + 2);
+  uint8_t* state = reinterpret_cast<uint8_t*>(fs + a.fcap);
 
-  const uint64_t off = a.toff[t];
-  const uint64_t L = a.toff[t + 1] - off;
-  const uint32_t n_ref = (L >= (uint64_t)k) ? (uint32_t)(L - k + 1) : 0;
+  const uint64_t L = a.toff[t + 1] - a.toff[t];
+  const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
   const uint32_t node_cap = a.node_cap[t];
-
-  if (n_ref == 0) {
-    if (lane == 0) {
-      a.status[t] = T_EMPTY; a.n_nodes[t] = 0; a.n_ref[t] = 0; a.probes[t] = 0; a.fetches[t] = 0;
-    }
-    return;
-  }
   const uint32_t nwords = (uint32_t)((L + 31) >> 5);
   const uint32_t nflag = (n_ref + 31) >> 5;
-  if (nwords + 1 > a.words_cap || nflag > a.flag_words || n_ref > node_cap ||
-      (uint64_t)n_ref * 4 > (uint64_t)cap * 3) {
-    if (lane == 0) {
-      a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.n_nodes[t] = 0; a.n_ref[t] = n_ref;
-      a.probes[t] = 0; a.fetches[t] = 0;
-    }
+  const uint32_t* flag = a.flagbits + a.fw_off[t];
+  if (nwords + 1 > a.words_cap || n_ref > node_cap || (uint64_t)n_ref * 4 > (uint64_t)cap * 3) {
+    if (lane == 0) a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG;
     return;
   }
+  if (a.dbg & 1u) return;
 
-  // ---- init per-target state -------------------------------------------------
+  // ---- per-target state: packed target + node set of the target's k-mers ------------
   for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
-  for (uint32_t w = lane; w < a.flag_words; w += 64) flag[w] = 0;
-  if (lane < 2) acc[lane] = 0;
-  // pack the target two bits per base, 32 bases per word, first base most significant
-  uint32_t bad = 0;
-  for (uint32_t w = lane; w <= nwords; w += 64) {
-    uint64_t v = 0;
-    if (w < nwords) {
-      const uint64_t p0 = (uint64_t)w << 5;
-      for (uint32_t j = 0; j < 32; ++j) {
-        uint32_t code = 0;
-        if (p0 + j < L) {
-          const uint32_t ch = a.bases[off + p0 + j] & 0xDFu;   // upper-case
-          bad |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
-          code = ((ch >> 1) ^ (ch >> 2)) & 3u;
-        }
-        v = (v << 2) | code;
-      }
-    }
-    words[w] = v;
+  {
+    const uint64_t wo = a.woff[t];
+    for (uint32_t w = lane; w <= nwords; w += 64) words[w] = a.packed[wo + w];
   }
   __syncthreads();
-  if (__any((int)bad)) {
-    if (lane == 0) {
-      a.status[t] = T_BAD_BASE; a.n_nodes[t] = 0; a.n_ref[t] = n_ref; a.probes[t] = 0; a.fetches[t] = 0;
-    }
-    return;
-  }
   auto kmer_at = [&](uint32_t i) -> uint64_t {
     const uint32_t w = i >> 5, sh = (i & 31) * 2;
     const uint64_t hi = words[w], lo = words[w + 1];
     const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
     return x >> (64 - 2 * k);
   };
-
-  // ---- phase A: register + one get_child per target k-mer --------------------
-  const bool no_extend = (a.max_stack == 0);   // every __extend returns at len(stack) > 0
-  uint64_t probes_l = 0;     // per-lane partial sums
-  uint32_t fetch_l = 0;
   uint32_t dup = 0;
-  for (uint32_t base = 0; base < n_ref; base += 64) {
-    const uint32_t i = base + lane;
-    if (i < n_ref) {
-      const uint64_t X = kmer_at(i);
-      bool was_new;
-      const int s = set_insert_lane(keys, cap, X, &was_new);
-      if (s >= 0 && was_new) state[s] = (uint8_t)ST_NODE;
-      if (s < 0 || !was_new) dup = 1;
-      a.node_kmer[nb + i] = X;
-      const uint4 c4 = forward_children(tab, X, &fetch_l);
-      uint32_t nextb = 4;
-      if (i + 1 < n_ref) {
-        nextb = (uint32_t)(kmer_at(i + 1) & 3);
-        a.node_cnt[nb + i + 1] = pick4(c4, nextb);
-      }
-      if (i == 0) a.node_cnt[nb] = query_one(tab, X, &fetch_l);
-      probes_l += 1;                                    // node_data[s] = jf.query(s)
-      if (!no_extend) {
-        const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
-        const bool trivial = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
-        if (trivial) {
-          probes_l += 4 + (mask ? 1 : 0);               // get_child + re-query of [seed]
-        } else {
-          atomicOr(&flag[i >> 5], 1u << (i & 31));
-        }
-      }
-    }
+  for (uint32_t i = lane; i < n_ref; i += 64) {
+    bool was_new;
+    const int s = set_insert_lane(keys, cap, kmer_at(i), &was_new);
+    if (s >= 0 && was_new) state[s] = (uint8_t)ST_NODE;
+    if (s < 0 || !was_new) dup = 1;
   }
   __syncthreads();
 
   uint32_t st = T_OK;
   uint32_t n_nodes = n_ref;
-  uint64_t probes_u = 0;     // wave-uniform part (phase B)
+  uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
-  else if (!no_extend && n_nodes > a.max_node) st = T_NODE_LIMIT;
 
-  // ---- phase B: exact DFS from every flagged seed, in target order ------------
-  if (st == T_OK && !no_extend) {
+  // ---- exact DFS from every flagged seed, in target order ----------------------------
+  if (st == T_OK) {
     uint32_t set_count = n_ref;
     const uint32_t set_limit = (uint32_t)(((uint64_t)cap * 3) >> 2);
     uint64_t steps = 0;
@@ -339,7 +411,8 @@ __global__ __launch_bounds__(64) void k_walk(WalkArgs a) {
               __syncthreads();
               bool wn;
               for (uint32_t j = lane; j < n_nodes; j += 64) {
-                const int s2 = set_insert_lane(keys, cap, a.node_kmer[nb + j], &wn);
+                const uint64_t kk = (j < n_ref) ? kmer_at(j) : a.node_kmer[nb + j];
+                const int s2 = set_insert_lane(keys, cap, kk, &wn);
                 if (s2 >= 0) state[s2] = (uint8_t)ST_NODE;
               }
               __syncthreads();
@@ -392,16 +465,13 @@ __global__ __launch_bounds__(64) void k_walk(WalkArgs a) {
     }
   }
 
-  // ---- results -----------------------------------------------------------------
-  atomicAdd(&acc[0], (unsigned long long)probes_l);
-  atomicAdd(&acc[1], (unsigned long long)fetch_l);
-  __syncthreads();
   if (lane == 0) {
     a.status[t] = st;
-    a.n_nodes[t] = n_nodes;
-    a.n_ref[t] = n_ref;
-    a.probes[t] = (uint64_t)acc[0] + probes_u;
-    a.fetches[t] = (uint64_t)acc[1] + fetch_u;
+    if (st != T_NEEDS_BIG) {     // a large-tier rerun restarts from the seed kernel's counters
+      a.n_nodes[t] = n_nodes;
+      a.probes[t] += probes_u;
+      a.fetches[t] += fetch_u;
+    }
   }
 }
 
