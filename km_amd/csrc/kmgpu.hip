@@ -384,6 +384,7 @@ struct km_batch {
   DevBuf<uint64_t> d_p_runbase;
   uint64_t path_pool = 0, run_pool = 0;
   // big tier
+  DevBuf<float> d_tref;               // shared reference-chain distances
   DevBuf<uint32_t> d_big_ids;
   DevBuf<unsigned char> d_big_ws;
   // host mirrors after sync
@@ -470,7 +471,7 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
-  b->d_big_ids.release(); b->d_big_ws.release();
+  b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release();
   for (int i = 0; i < 3; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   delete b;
   return KM_OK;
@@ -518,6 +519,19 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
 
 static int push_layout(km_batch* b, hipStream_t st) {
   const uint32_t n = b->n_targets;
+  {
+    // tref[j] = distance of reference node j from the source along the reference chain,
+    // accumulated exactly as Graph.py does: float32 0 + 0.01f, then + 0.01f per hop
+    const uint32_t need = b->max_len + 2;
+    if (b->d_tref.n < need) {
+      int rc = b->d_tref.alloc(std::max<uint64_t>(need, 4096));
+      if (rc != KM_OK) return rc;
+      std::vector<float> h(b->d_tref.n);
+      volatile float acc = 0.0f;
+      for (size_t j = 0; j < h.size(); ++j) { acc = acc + 0.01f; h[j] = acc; }
+      HIPCHK(hipMemcpy(b->d_tref.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
   HIPCHK(hipMemcpyAsync(b->d_toff.p, b->h_toff.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_woff.p, b->h_woff.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_fw_off.p, b->h_fw_off.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -621,6 +635,8 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.p_mincov = b->d_p_mincov.p;
   g.r_start = b->d_r_start.p;
   g.r_len = b->d_r_len.p;
+  g.tref = b->d_tref.p;
+  g.tref_len = (uint32_t)std::min<uint64_t>(b->d_tref.n, 0xFFFFFFFFull);
   g.g_ws = nullptr;
   g.g_stride = 0;
   const char* dbg = getenv("KM_DEBUG_FLAGS");
