@@ -100,32 +100,22 @@ def main():
     T = args.targets
     # ---- rank 0 generates the whole job: world*T targets, one table --------------------
     t_gen = time.perf_counter()
+    case = None
     if rank == 0:
         case = synth.make_case(n_targets=T * world, length=args.length, k=K, n_keys=args.keys,
                                seed=synth.HEADLINE_SEED, exact_pad=False)
-        n_rec = int(case["keys"].size)
-        meta = torch.tensor([n_rec], dtype=torch.int64, device=dev)
-    else:
-        case = None
-        meta = torch.zeros(1, dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(meta, 0)
-    n_rec = int(meta.item())
     t_gen = time.perf_counter() - t_gen
 
     # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------
+    from km_amd import dist as kd
     t_up = time.perf_counter()
+    d_keys, d_cnts, n_rec, _k, _canon = kd.broadcast_records(
+        case["keys"] if rank == 0 else None, case["counts"] if rank == 0 else None, K, True, dev)
     if rank == 0:
-        d_keys = torch.from_numpy(case["keys"].view(np.int64)).to(dev)
-        d_cnts = torch.from_numpy(case["counts"].view(np.int32)).to(dev)
         bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(dev)
     else:
-        d_keys = torch.empty(n_rec, dtype=torch.int64, device=dev)
-        d_cnts = torch.empty(n_rec, dtype=torch.int32, device=dev)
         bases_all = torch.empty((T * world, args.length), dtype=torch.uint8, device=dev)
     if world > 1:
-        dist.broadcast(d_keys, 0)
-        dist.broadcast(d_cnts, 0)
         dist.broadcast(bases_all, 0)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t_up

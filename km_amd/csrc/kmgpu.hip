@@ -188,7 +188,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   HIPCHK(hipSetDevice(device));
   // every record enters at most two groups; keep the load factor <= 0.5
   uint64_t entries = (h->canonical ? 2 : 1) * n;
-  // KM_TABLE_LOAD: target load factor of the HBM table (default 0.5; HBM is plentiful)
+  // KM_TABLE_LOAD: target load factor of the HBM table (HBM capacity is plentiful)
   double load = 0.5;
   if (const char* lf = getenv("KM_TABLE_LOAD")) { double v = atof(lf); if (v >= 0.05 && v <= 0.9) load = v; }
   uint64_t n_slots = std::max<uint64_t>(1024, (uint64_t)((double)entries / load) + 1);
@@ -360,9 +360,10 @@ struct km_batch {
   DevBuf<uint64_t> d_woff, d_packed;   // 2-bit packed targets (k_pack)
   std::vector<uint64_t> h_woff;
   // k_seed work items and flag bitmaps
-  DevBuf<uint32_t> d_item_t, d_item_start, d_flagbits, d_tflag, d_flagged, d_nflagged;
+  DevBuf<uint32_t> d_item_off, d_flagbits, d_tflag, d_flagged, d_nflagged;
+  DevBuf<uint64_t> d_items;
   DevBuf<uint64_t> d_fw_off;
-  std::vector<uint32_t> h_item_t, h_item_start;
+  std::vector<uint32_t> h_item_off;
   std::vector<uint64_t> h_fw_off;
   uint32_t n_items = 0;
   bool big_walk_done = false;
@@ -384,6 +385,7 @@ struct km_batch {
   DevBuf<uint64_t> d_p_runbase;
   uint64_t path_pool = 0, run_pool = 0;
   // big tier
+  DevBuf<unsigned char> d_frames;     // fast-tier DFS stack frames, one slice per target
   DevBuf<float> d_tref;               // shared reference-chain distances
   DevBuf<uint32_t> d_big_ids;
   DevBuf<unsigned char> d_big_ws;
@@ -420,8 +422,8 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_toff.alloc((uint64_t)max_targets + 1));
   A(b->d_woff.alloc((uint64_t)max_targets + 1));
   A(b->d_packed.alloc(max_total_bases / 32 + 2 * (uint64_t)max_targets + 2));
-  A(b->d_item_t.alloc(max_total_bases / SEED_BLOCK + (uint64_t)max_targets + 1));
-  A(b->d_item_start.alloc(max_total_bases / SEED_BLOCK + (uint64_t)max_targets + 1));
+  A(b->d_items.alloc(16 * (max_total_bases / SEED_BLOCK + (uint64_t)max_targets + 1)));
+  A(b->d_item_off.alloc((uint64_t)max_targets + 1));
   A(b->d_flagbits.alloc(max_total_bases / 32 + (uint64_t)max_targets + 1));
   A(b->d_fw_off.alloc((uint64_t)max_targets + 1));
   A(b->d_tflag.alloc(max_targets));
@@ -464,14 +466,14 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
   b->d_bases.release(); b->d_toff.release(); b->d_woff.release(); b->d_packed.release();
-  b->d_item_t.release(); b->d_item_start.release(); b->d_flagbits.release(); b->d_fw_off.release();
+  b->d_items.release(); b->d_item_off.release(); b->d_flagbits.release(); b->d_fw_off.release();
   b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
   b->d_npaths.release(); b->d_pathbase.release(); b->d_probes.release(); b->d_fetches.release();
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
-  b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release();
+  b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release();
   for (int i = 0; i < 3; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   delete b;
   return KM_OK;
@@ -488,8 +490,7 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
   b->h_toff.assign(n + 1, 0);
   b->h_woff.assign(n + 1, 0);
   b->h_fw_off.assign(n + 1, 0);
-  b->h_item_t.clear();
-  b->h_item_start.clear();
+  b->h_item_off.assign(n + 1, 0);
   b->h_node_base.assign(n, 0);
   b->h_node_cap.assign(n, 0);
   uint64_t pool = 0;
@@ -502,7 +503,7 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
     b->h_woff[t + 1] = b->h_woff[t] + (L + 31) / 32 + 1;
     const uint32_t n_ref = (L >= (uint64_t)k) ? (uint32_t)(L - k + 1) : 0;
     b->h_fw_off[t + 1] = b->h_fw_off[t] + (n_ref + 31) / 32;
-    for (uint32_t st0 = 0; st0 < n_ref; st0 += SEED_BLOCK) { b->h_item_t.push_back(t); b->h_item_start.push_back(st0); }
+    b->h_item_off[t + 1] = b->h_item_off[t] + (n_ref + SEED_BLOCK - 1) / SEED_BLOCK;
     b->h_node_base[t] = pool;
     b->h_node_cap[t] = n_ref + FAST_EXTRA;
     pool += (uint64_t)n_ref + FAST_EXTRA;
@@ -510,7 +511,7 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
   }
   b->h_toff[n] = total;
   b->node_pool_used = pool;
-  b->n_items = (uint32_t)b->h_item_t.size();
+  b->n_items = b->h_item_off[n];
   b->n_targets = n;
   b->total_bases = total;
   b->max_len = max_len;
@@ -535,10 +536,7 @@ static int push_layout(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemcpyAsync(b->d_toff.p, b->h_toff.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_woff.p, b->h_woff.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_fw_off.p, b->h_fw_off.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-  if (b->n_items) {
-    HIPCHK(hipMemcpyAsync(b->d_item_t.p, b->h_item_t.data(), (uint64_t)b->n_items * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_item_start.p, b->h_item_start.data(), (uint64_t)b->n_items * 4, hipMemcpyHostToDevice, st));
-  }
+  HIPCHK(hipMemcpyAsync(b->d_item_off.p, b->h_item_off.data(), (uint64_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_node_base.p, b->h_node_base.data(), (uint64_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_node_cap.p, b->h_node_cap.data(), (uint64_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -584,8 +582,8 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.max_stack = b->p.max_stack;
   a.max_break = b->p.max_break;
   a.max_node = b->p.max_node;
-  a.item_t = b->d_item_t.p;
-  a.item_start = b->d_item_start.p;
+  a.items = b->d_items.p;
+  a.item_off = b->d_item_off.p;
   a.n_items = b->n_items;
   a.flagbits = b->d_flagbits.p;
   a.fw_off = b->d_fw_off.p;
@@ -672,7 +670,13 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   wa.words_cap = round_up((b->max_len + 31) / 32 + 1, 2);
   wa.fcap = round_up(b->p.max_stack + 2, 2);
   wa.bcap = b->p.max_break + 1;
-  const uint64_t wl = walk_ws_bytes(wa.hs_cap, wa.words_cap, wa.fcap, wa.bcap);
+  const uint64_t wl = walk_lds_bytes(wa.hs_cap, wa.words_cap, wa.bcap);
+  wa.f_stride = walk_frame_bytes(wa.fcap);
+  {
+    int rc = b->d_frames.alloc((uint64_t)b->n_targets * wa.f_stride);
+    if (rc != KM_OK) return rc;
+  }
+  wa.f_ws = b->d_frames.p;
   b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
   GraphArgs& ga = b->ga;
   fill_graph_args(b, ga);

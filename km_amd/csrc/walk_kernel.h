@@ -65,9 +65,11 @@ struct WalkArgs {
   double ratio;
   int64_t n_cutoff;
   uint32_t max_stack, max_break, max_node;
-  // k_seed work items: (target, first seed)
-  const uint32_t* item_t;
-  const uint32_t* item_start;
+  // k_seed work items: one self-contained 128-byte record per SEED_BLOCK seeds, written
+  // by k_pack: [0] target | first seed << 32, [1] n_ref | valid << 32, [2] node base,
+  // [3] flag-word offset, [4..15] the 12 packed words covering the item's k-mers
+  uint64_t* items;
+  const uint32_t* item_off;   // first item of each target
   uint32_t n_items;
   // flagged seeds / targets
   uint32_t* flagbits;         // per target bitmap, words at fw_off[t]
@@ -97,19 +99,28 @@ struct WalkArgs {
   uint32_t dbg;         // diagnostic ablation flags (KM_DEBUG_FLAGS): 1 = skip k_dfs work
   unsigned char* g_ws;  // BIG only
   uint64_t g_stride;    // BIG only: bytes per block
+  unsigned char* f_ws;  // fast tier: global scratch for the DFS stack frames (per block)
+  uint64_t f_stride;
 };
 
-__host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t words_cap,
-                                                  uint32_t fcap, uint32_t bcap) {
+// Per-target k_dfs state.  BIG tier: everything in one global block.  Fast tier: node
+// set, packed target and branch frames in LDS (walk_lds_bytes), stack frames in a
+// global scratch (walk_frame_bytes) — frames are written on every push but read back
+// only on a rejoin or an unwind.
+__host__ __device__ inline uint64_t walk_frame_bytes(uint32_t fcap) {
+  return (((uint64_t)fcap * 16) + 15) & ~15ull;       // k-mer 8 + count 4 + set slot 4
+}
+__host__ __device__ inline uint64_t walk_lds_bytes(uint32_t hs_cap, uint32_t words_cap, uint32_t bcap) {
   uint64_t b = 0;
   b += (uint64_t)hs_cap * 8;       // keys
   b += (uint64_t)words_cap * 8;    // packed target
-  b += (uint64_t)fcap * 8;         // frame k-mers
   b += (uint64_t)bcap * 32;        // branch frames
-  b += (uint64_t)fcap * 4;         // frame counts
-  b += (uint64_t)fcap * 4;         // frame set slots
   b += (uint64_t)hs_cap;           // slot states
   return (b + 15) & ~15ull;
+}
+__host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t words_cap,
+                                                  uint32_t fcap, uint32_t bcap) {
+  return walk_lds_bytes(hs_cap, words_cap, bcap) + walk_frame_bytes(fcap);
 }
 
 __device__ inline uint32_t set_home(uint64_t key, uint32_t cap) {
@@ -189,11 +200,30 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
   const uint64_t fwo = a.fw_off[t];
   for (uint32_t w = lane; w < (n_ref + 31) / 32; w += 64) a.flagbits[fwo + w] = 0;
   const int any_bad = __any((int)bad);
+  uint32_t st = T_OK;
+  if (n_ref == 0) st = T_EMPTY;
+  else if (any_bad) st = T_BAD_BASE;
+  else if (a.max_stack > 0 && n_ref > a.max_node) st = T_NODE_LIMIT;  // first __extend call exits
+  __syncthreads();                                   // packed words of this target are visible
+  {
+    const uint32_t n_it = (n_ref + SEED_BLOCK - 1) / SEED_BLOCK;
+    const uint64_t nbase = a.node_base[t];
+    uint64_t* rec0 = a.items + 16ull * a.item_off[t];
+    for (uint32_t x = lane; x < n_it * 16; x += 64) {
+      const uint32_t q = x >> 4, f = x & 15;
+      uint64_t v;
+      if (f == 0) v = (uint64_t)t | ((uint64_t)(q * SEED_BLOCK) << 32);
+      else if (f == 1) v = (uint64_t)n_ref | ((uint64_t)(st == T_OK ? 1u : 0u) << 32);
+      else if (f == 2) v = nbase;
+      else if (f == 3) v = fwo;
+      else {
+        const uint32_t w = q * (SEED_BLOCK / 32) + (f - 4);
+        v = (w <= nwords) ? a.packed[wo + w] : 0ull;
+      }
+      rec0[x] = v;
+    }
+  }
   if (lane == 0) {
-    uint32_t st = T_OK;
-    if (n_ref == 0) st = T_EMPTY;
-    else if (any_bad) st = T_BAD_BASE;
-    else if (a.max_stack > 0 && n_ref > a.max_node) st = T_NODE_LIMIT;  // first __extend call exits
     a.status[t] = st;
     a.n_ref[t] = n_ref;
     a.n_nodes[t] = (st == T_OK || st == T_NODE_LIMIT) ? n_ref : 0;
@@ -206,39 +236,30 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
 
 // ---------------------------------------------------------------------------- k_seed
 __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
-  __shared__ uint64_t words[SEED_BLOCK / 32 + 4];
-  const uint32_t item = blockIdx.x;
-  const uint32_t t = a.item_t[item];
-  if (a.status[t] != T_OK) return;
+  static_assert(SEED_BLOCK == 256, "the item record holds 12 words = 256 seeds + k - 1 + 1 bases");
+  const uint64_t* rec = a.items + 16ull * blockIdx.x;
+  const uint64_t h0 = rec[0], h1 = rec[1];
+  if ((uint32_t)(h1 >> 32) == 0u) return;                  // target not walkable (status != OK)
   const TableView tab = a.tab;
   const int k = tab.k;
-  const uint32_t start = a.item_start[item];
-  const uint32_t n_ref = a.n_ref[t];
+  const uint32_t t = (uint32_t)h0;
+  const uint32_t start = (uint32_t)(h0 >> 32);
+  const uint32_t n_ref = (uint32_t)h1;
   const uint32_t i = start + threadIdx.x;
-  const uint64_t wo = a.woff[t];
-  // this block needs bases [start, start + SEED_BLOCK + k): at most SEED_BLOCK/32 + 3 words
-  const uint32_t w0 = start >> 5;
-  if (threadIdx.x < SEED_BLOCK / 32 + 4) {
-    const uint64_t L = a.toff[t + 1] - a.toff[t];
-    const uint32_t nwords = (uint32_t)((L + 31) >> 5);
-    const uint32_t w = w0 + threadIdx.x;
-    words[threadIdx.x] = (w <= nwords) ? a.packed[wo + w] : 0ull;
-  }
-  __syncthreads();
   unsigned long long probes_l = 0;
   uint32_t fetch_l = 0;
   if (i < n_ref) {
-    const uint64_t nb = a.node_base[t];
-    const uint32_t w = (i >> 5) - w0, sh = (i & 31) * 2;
-    const uint64_t hi = words[w], lo = words[w + 1];
+    const uint64_t nb = rec[2];
+    const uint32_t w = threadIdx.x >> 5, sh = (threadIdx.x & 31) * 2;   // start is a multiple of 256
+    const uint64_t hi = rec[4 + w], lo = rec[5 + w];
     const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
     const uint64_t X = x >> (64 - 2 * k);
     a.node_kmer[nb + i] = X;
     const uint4 c4 = forward_children(tab, X, &fetch_l);
     uint32_t nextb = 4;
     if (i + 1 < n_ref) {
-      const uint32_t p = i + (uint32_t)k;                 // last base of ref[i+1]
-      nextb = (uint32_t)(words[(p >> 5) - w0] >> (62 - 2 * (p & 31))) & 3u;
+      const uint32_t p = threadIdx.x + (uint32_t)k;       // last base of ref[i+1], item-relative
+      nextb = (uint32_t)(rec[4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
       a.node_cnt[nb + i + 1] = pick4(c4, nextb);
     }
     if (i == 0) a.node_cnt[nb] = query_one(tab, X, &fetch_l);
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
       if (trivial) {
         probes_l += 4 + (mask ? 1 : 0);                    // get_child + re-query of [seed]
       } else {
-        atomicOr(&a.flagbits[a.fw_off[t] + (i >> 5)], 1u << (i & 31));
+        atomicOr(&a.flagbits[rec[3] + (i >> 5)], 1u << (i & 31));
         if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
       }
     }
@@ -279,16 +300,31 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   const int k = tab.k;
 
   unsigned char* wsb;
-  if constexpr (BIG) wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
-  else wsb = smem;
+  unsigned char* fwb;
+  if constexpr (BIG) {
+    wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
+    fwb = wsb + walk_lds_bytes(a.hs_cap, a.words_cap, a.bcap);
+  } else {
+    wsb = smem;
+    fwb = a.f_ws + (uint64_t)blockIdx.x * a.f_stride;
+  }
   const uint32_t cap = a.hs_cap;
   uint64_t* keys = reinterpret_cast<uint64_t*>(wsb);
   uint64_t* words = keys + cap;
-  uint64_t* fk = words + a.words_cap;
-  BranchFrame* bf = reinterpret_cast<BranchFrame*>(fk + a.fcap);
-  uint32_t* fc = reinterpret_cast<uint32_t*>(bf + a.bcap);
+  BranchFrame* bf = reinterpret_cast<BranchFrame*>(words + a.words_cap);
+  uint8_t* state = reinterpret_cast<uint8_t*>(bf + a.bcap);
+  uint64_t* fk = reinterpret_cast<uint64_t*>(fwb);
+  uint32_t* fc = reinterpret_cast<uint32_t*>(fk + a.fcap);
   uint32_t* fs = fc + a.fcap;
-  uint8_t* state = reinterpret_cast<uint8_t*>(fs + a.fcap);
+  // Single-wave workgroup.  step_sync: orders LDS traffic between lanes (the node set,
+  // states, branch frames) — LDS executes a wave's operations in order, so only the
+  // compiler must be held back.  mem_sync: additionally makes lane 0's frame stores
+  // (global memory) visible before other lanes read them.
+  auto step_sync = [&]() {
+    if constexpr (BIG) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto mem_sync = [&]() { __syncthreads(); };
 
   const uint64_t L = a.toff[t + 1] - a.toff[t];
   const uint32_t n_ref = a.n_ref[t];
@@ -349,7 +385,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         uint32_t depth = 1, reg = 1, bsp = 0, parent_brk = 0, mask = 0, brk = 0;
         uint4 c4 = make_uint4(0, 0, 0, 0);
         bool need_expand = true;
-        __syncthreads();
+        step_sync();
         while (true) {
           if (++steps > DFS_STEP_LIMIT) { st = T_INTERNAL; break; }
           if (need_expand) {
@@ -367,6 +403,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           if (mask == 0) {
             if (bsp == 0) break;                         // DFS from this seed is done
             --bsp;
+            mem_sync();
             const BranchFrame f = bf[bsp];
             for (uint32_t j = f.depth + lane; j < depth; j += 64) {
               const uint32_t s = fs[j];
@@ -376,7 +413,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             if (reg > depth) reg = depth;
             cur = fk[depth - 1];
             c4 = f.c4; mask = f.mask; brk = f.brk;
-            __syncthreads();
+            step_sync();
             continue;
           }
           const uint32_t c = (uint32_t)__ffs((int)mask) - 1;
@@ -393,6 +430,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             if (reg < depth) {
               const uint32_t add = depth - reg;
               if (n_nodes + add > node_cap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
+              mem_sync();
               for (uint32_t j = reg + lane; j < depth; j += 64) {
                 a.node_kmer[nb + n_nodes + (j - reg)] = fk[j];
                 a.node_cnt[nb + n_nodes + (j - reg)] = fc[j];
@@ -400,7 +438,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               }
               n_nodes += add;
               reg = depth;
-              __syncthreads();
+              step_sync();
             }
           } else if (depth + 1 <= a.max_stack) {
             // __extend(stack + [child], breaks)
@@ -448,16 +486,17 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             ++depth;
             cur = child;
             need_expand = true;
-            __syncthreads();
+            step_sync();
           }
           // else: the child's __extend returns at once (len(stack) > max_stack)
         }
         if (st != T_OK) break;
+        mem_sync();
         for (uint32_t j = 1 + lane; j < depth; j += 64) {
           const uint32_t s = fs[j];
           if (state[s] == ST_ONSTACK) state[s] = (uint8_t)ST_POPPED;
         }
-        __syncthreads();
+        step_sync();
         // the next seed's __extend call (there is one unless this was the last
         // target k-mer) checks the node limit first
         if (n_nodes > a.max_node && i + 1 < n_ref) st = T_NODE_LIMIT;

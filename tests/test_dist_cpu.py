@@ -1,0 +1,82 @@
+"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo): one broadcast of the
+database records, target sharding, ordered gather.  The per-shard compute is done
+by the oracle here (no GPU in this container); on a GPU box the same plumbing
+drives the HIP path (bench.py, km_amd/dist.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import torch.distributed as dist
+from km_amd import dist as kd
+from oracle import jf_reader as jr, km_oracle as ko
+
+os.chdir(%(here)r)
+rank, local_rank, world = kd.init(backend="gloo")
+assert world == 2 and dist.get_backend() == "gloo"
+cat = sorted(os.listdir("./data/catalog/GRCh38"))
+targets = [(os.path.splitext(f)[0], ko.read_fasta_concat("./data/catalog/GRCh38/" + f)) for f in cat]
+DB = "./data/jf/03H116_ITD.jf"
+
+def load(path):
+    d = jr.read_jf(path)
+    return d["keys"], d["counts"], d["k"], d["canonical"]
+
+seen = {}
+def analyse(d_keys, d_cnts, n, k, canonical, mine):
+    keys = d_keys.numpy().view(np.uint64)
+    cnts = d_cnts.numpy().view(np.uint32)
+    seen["n"] = n
+    db = ko.KmerDB(DB, cutoff=0.05, n_cutoff=5,
+                   records={"k": k, "canonical": canonical, "keys": keys, "counts": cnts})
+    return [ko.target_rows(ko.analyse_target(seq, name, db), DB) for name, seq in mine]
+
+rows = kd.find_mutation_sharded(targets, DB, analyse, load)
+lo, hi = kd.shard_range(len(targets), rank, world)
+out = {"rank": rank, "shard": [lo, hi], "n_records": seen["n"]}
+if rank == 0:
+    out["rows"] = [r for per_target in rows for r in per_target]
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_covers_everything():
+    from km_amd import dist as kd
+    for n in (0, 1, 7, 9, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [kd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "here": HERE})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() % 2000)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = [json.loads(l[len("RESULT "):]) for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert len(res) == 2
+    by_rank = {r["rank"]: r for r in res}
+    assert by_rank[0]["shard"] == [0, 5] and by_rank[1]["shard"] == [5, 9]
+    assert by_rank[0]["n_records"] == by_rank[1]["n_records"] == 2560      # the broadcast arrived
+    gold = json.load(open(os.path.join(HERE, "golden", "fixtures_tsv.json")))
+    case = [c for c in gold["cases"] if len(c["targets"]) == 9 and c["db"].endswith("03H116_ITD.jf")][0]
+    assert by_rank[0]["rows"] == case["lines"][11:]      # after the 10 '#' lines + header

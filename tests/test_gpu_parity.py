@@ -234,3 +234,71 @@ def test_empty_batch_and_ragged():
     for steps, br, nodes in [(0, 10, 10000), (1, 10, 10000), (2, 0, 10000), (70, 1, 10000),
                              (500, 10, 315), (500, 10, 316), (500, 10, 346), (500, 10, 347)]:
         _compare_with_oracle(jf, cpu, [("flt3", seq)], steps, br, nodes)
+
+
+# ------------------------------------------------------------------ CLI drop-in
+def test_cli_find_mutation_and_min_cov(capsys):
+    """`python -m km_amd find_mutation` prints what `km find_mutation` prints."""
+    import argparse
+    from km_amd import cli
+    case = _load("fixtures_tsv.json")["cases"][1]            # FLT3-ITD x 03H116
+    p = argparse.ArgumentParser()
+    cli.add_find_mutation_args(p)
+    args = p.parse_args(case["targets"] + [case["db"]])
+    assert list(vars(args).keys()) == ["count", "ratio", "steps", "branchs", "nodes", "graphical",
+                                       "verbose", "debug", "target_fn", "jellyfish_fn"]
+    cli.main_find_mut(args)
+    out = capsys.readouterr().out.splitlines()
+    assert out[-1].startswith("#Elapsed time:")
+    assert out[:-1] == case["lines"]
+    # line 13 is what the reference's own test indexes (km/tests/test_main.py:269)
+    assert out[13].split("\t")[2] == "ITD"
+    ns = argparse.Namespace(target_fn="./data/catalog/GRCh38/FLT3-ITD_exons_13-15.fa",
+                            jellyfish_fn=["./data/jf/03H112_IandI.jf"])
+    cli.main_min_cov(ns)
+    got = capsys.readouterr().out.splitlines()
+    assert got[0] == "DB\tcount\tlength\tmin\tmax\tmean\tkmer_nb\tkmer_nb_0"
+    assert got[1] == "./data/jf/03H112_IandI.jf\t275596\t345\t618\t1368\t874.91\t315\t0"
+
+
+# ------------------------------------------------------------------ properties at size
+def test_properties_mid_size():
+    """Invariants that do not need the oracle, on 2000 targets / 1.5 M keys: determinism,
+    path structure, min coverage, agreement of the walk's counts with the probe kernel."""
+    case = synth.make_case(n_targets=2000, length=500, n_keys=1_500_000, seed=99, exact_pad=False)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    b = kmlib.Batch(db, max_targets=2000, max_total_bases=2000 * 500)
+    seqs = [km.decode(r) for r in case["targets"]]
+    b.set_targets(seqs)
+    b.run()
+    r1 = b.fetch()
+    b.run()
+    r2 = b.fetch()
+    for key in ("status", "n_ref", "probes", "node_off", "node_kmer", "node_count", "path_off",
+                "run_off", "run_start", "run_len", "path_len", "path_min_cov"):
+        assert (r1[key] == r2[key]).all(), key
+    assert (r1["status"] == 0).all() and (r1["n_ref"] == 470).all()
+    # counts stored by the walk == Jellyfish.query of the same k-mers
+    assert (db.query(r1["node_kmer"]) == r1["node_count"]).all()
+    # the first n_ref nodes of every target are its own k-mers, in order
+    ref = km.sliding_kmers(case["targets"], 31)
+    noff = r1["node_off"].astype(np.int64)
+    first = noff[:-1, None] + np.arange(470)[None, :]
+    assert (r1["node_kmer"][first] == ref).all()
+    n_var = 0
+    for t in range(2000):
+        pa, pe = int(r1["path_off"][t]), int(r1["path_off"][t + 1])
+        assert pe > pa
+        cnt = r1["node_count"][noff[t]:noff[t + 1]]
+        kms = r1["node_kmer"][noff[t]:noff[t + 1]]
+        paths = [kmlib.expand_path(r1, p) for p in range(pa, pe)]
+        assert paths[0].tolist() == list(range(470))            # the reference path sorts first
+        assert paths == sorted(paths, key=lambda x: x.tolist())
+        for p, idx in zip(range(pa, pe), paths):
+            assert idx[0] == 0 and idx[-1] == 469                # source -> sink
+            assert int(r1["path_len"][p]) == len(idx)
+            assert int(r1["path_min_cov"][p]) == int(cnt[idx].min())
+            # consecutive nodes overlap by k-1
+            assert ((kms[idx[:-1]] & np.uint64((1 << 60) - 1)) == (kms[idx[1:]] >> np.uint64(2))).all()
+        n_var += (pe - pa) > 1
+    assert 400 < n_var < 800                                      # ~30 % of targets carry a variant
