@@ -84,7 +84,8 @@ typedef struct {
   uint64_t logical_probes; /* reference-semantics Jellyfish.query calls        */
   uint64_t table_fetches;  /* 32-byte table slots actually read by the walk    */
   uint32_t n_big_tier;     /* targets that needed the large-workspace pass     */
-  uint32_t reserved;
+  uint32_t n_flagged;      /* targets with at least one non-trivial seed       */
+  uint64_t seed_probes;    /* logical probes answered by the k_seed kernel     */
 } km_batch_sizes_t;
 
 /* Host-side result arrays, all caller-allocated (numpy).  Any pointer may be
@@ -177,9 +178,10 @@ int km_batch_run(km_batch_t* b, int stages, void* stream);
 int km_batch_sync(km_batch_t* b);
 int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* sizes);
 int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
-/* Average duration (ms) of the last run's kernels measured with HIP events on the
- * launch stream: [0] walk, [1] graph, [2] whole run. */
-int km_batch_timings(km_batch_t* b, float* ms3);
+/* Durations (ms) of the last run measured with HIP events on the launch stream:
+ * [0] walk stage (k_pack + k_seed + k_dfs), [1] graph stage, [2] whole run,
+ * [3] the k_seed kernel alone. */
+int km_batch_timings(km_batch_t* b, float* ms4);
 
 /* ---- misc ---------------------------------------------------------------- */
 const char* km_strerror(int code);

@@ -361,6 +361,7 @@ struct km_batch {
   std::vector<uint64_t> h_woff;
   // k_seed work items and flag bitmaps
   DevBuf<uint32_t> d_item_off, d_flagbits, d_tflag, d_flagged, d_nflagged;
+  DevBuf<unsigned long long> d_dfs_probes;
   DevBuf<uint64_t> d_items;
   DevBuf<uint64_t> d_fw_off;
   std::vector<uint32_t> h_item_off;
@@ -392,6 +393,7 @@ struct km_batch {
   // host mirrors after sync
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
   std::vector<uint64_t> h_probes, h_fetches;
+  std::vector<unsigned long long> h_dfs_probes;
   unsigned long long h_counters[4] = {0, 0, 0, 0};
   uint32_t n_big = 0;
   // geometry of the last launch
@@ -400,8 +402,10 @@ struct km_batch {
   GraphArgs ga{};
   uint32_t walk_lds = 0, graph_lds = 0;
   // timing
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  float ms[3] = {0, 0, 0};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float ms[4] = {0, 0, 0, 0};
+  unsigned long long h_seed_probes = 0;
+  uint32_t h_nflagged = 0;
 };
 
 extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t max_targets,
@@ -429,6 +433,7 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_tflag.alloc(max_targets));
   A(b->d_flagged.alloc(max_targets));
   A(b->d_nflagged.alloc(1));
+  A(b->d_dfs_probes.alloc(max_targets));
   A(b->d_node_base.alloc(max_targets));
   A(b->d_node_cap.alloc(max_targets));
   A(b->d_n_nodes.alloc(max_targets));
@@ -453,7 +458,7 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_r_start.alloc(b->run_pool));
   A(b->d_r_len.alloc(b->run_pool));
   if (rc == KM_OK) {
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 5; ++i)
       if (hipEventCreate(&b->ev[i]) != hipSuccess) rc = fail(KM_E_HIP, "hipEventCreate failed");
   }
   if (rc != KM_OK) { km_batch_destroy(b); return rc; }
@@ -467,14 +472,14 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   (void)hipDeviceSynchronize();
   b->d_bases.release(); b->d_toff.release(); b->d_woff.release(); b->d_packed.release();
   b->d_items.release(); b->d_item_off.release(); b->d_flagbits.release(); b->d_fw_off.release();
-  b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_node_base.release(); b->d_node_cap.release();
+  b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_dfs_probes.release(); b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
   b->d_npaths.release(); b->d_pathbase.release(); b->d_probes.release(); b->d_fetches.release();
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
   b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release();
-  for (int i = 0; i < 3; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   delete b;
   return KM_OK;
 }
@@ -601,6 +606,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.n_ref = b->d_n_ref.p;
   a.status = b->d_status.p;
   a.probes = reinterpret_cast<unsigned long long*>(b->d_probes.p);
+  a.dfs_probes = b->d_dfs_probes.p;
   a.fetches = reinterpret_cast<unsigned long long*>(b->d_fetches.p);
   a.g_ws = nullptr;
   a.g_stride = 0;
@@ -691,8 +697,10 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   if (stages & KM_STAGE_WALK) {
     HIPCHK(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
+    HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
       hipLaunchKernelGGL(k_seed, dim3(b->n_items), dim3(SEED_BLOCK), 0, st, wa);
+    HIPCHK(hipEventRecord(b->ev[4], st));
     if (b->fast_ok)
       hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     HIPCHK(hipGetLastError());
@@ -704,6 +712,8 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     return fail(KM_E_STATE, "graph stage requested before the walk stage");
   } else {
     HIPCHK(hipEventRecord(b->ev[0], st));
+    HIPCHK(hipEventRecord(b->ev[3], st));
+    HIPCHK(hipEventRecord(b->ev[4], st));
     HIPCHK(hipEventRecord(b->ev[1], st));
   }
   // the graph kernel also hosts the duplicate-k-mer check, so it always runs
@@ -727,6 +737,8 @@ static int pull_status(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemcpyAsync(b->h_n_ref.data(), b->d_n_ref.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(b->h_probes.data(), b->d_probes.p, (uint64_t)n * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(b->h_fetches.data(), b->d_fetches.p, (uint64_t)n * 8, hipMemcpyDeviceToHost, st));
+  b->h_dfs_probes.resize(n);
+  HIPCHK(hipMemcpyAsync(b->h_dfs_probes.data(), b->d_dfs_probes.p, (uint64_t)n * 8, hipMemcpyDeviceToHost, st));
   if (b->ran_graph) {
     HIPCHK(hipMemcpyAsync(b->h_gstatus.data(), b->d_gstatus.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_npaths.data(), b->d_npaths.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -734,6 +746,11 @@ static int pull_status(km_batch* b, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(b->h_counters, b->d_counters.p, 32, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(hipStreamSynchronize(st));
+  b->h_seed_probes = 0;
+  for (uint32_t t = 0; t < n; ++t) {
+    b->h_seed_probes += b->h_probes[t];
+    b->h_probes[t] += b->h_dfs_probes[t];
+  }
   return KM_OK;
 }
 
@@ -870,6 +887,8 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   (void)hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&b->ms[2], b->ev[0], b->ev[2]);
+  (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
+  HIPCHK(hipMemcpy(&b->h_nflagged, b->d_nflagged.p, 4, hipMemcpyDeviceToHost));
   int rc = pull_status(b, st);
   if (rc != KM_OK) return rc;
   const uint32_t n = b->n_targets;
@@ -924,11 +943,12 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   return KM_OK;
 }
 
-extern "C" int km_batch_timings(km_batch_t* b, float* ms3) {
+extern "C" int km_batch_timings(km_batch_t* b, float* ms4) {
+  float* ms3 = ms4;
   if (!b || !ms3) return fail(KM_E_ARG, "null argument");
   int rc = km_batch_sync(b);
   if (rc != KM_OK) return rc;
-  ms3[0] = b->ms[0]; ms3[1] = b->ms[1]; ms3[2] = b->ms[2];
+  ms3[0] = b->ms[0]; ms3[1] = b->ms[1]; ms3[2] = b->ms[2]; ms3[3] = b->ms[3];
   return KM_OK;
 }
 
@@ -940,6 +960,8 @@ extern "C" int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* s) {
   memset(s, 0, sizeof *s);
   s->n_targets = b->n_targets;
   s->n_big_tier = b->n_big;
+  s->n_flagged = b->h_nflagged;
+  s->seed_probes = b->h_seed_probes;
   uint64_t paths = 0;
   for (uint32_t t = 0; t < b->n_targets; ++t) {
     if (b->h_status[t] == T_OK || b->h_status[t] == T_NODE_LIMIT) s->n_nodes += b->h_n_nodes[t];

@@ -89,7 +89,8 @@ struct WalkArgs {
   uint32_t* n_nodes;
   uint32_t* n_ref;
   uint32_t* status;
-  unsigned long long* probes;
+  unsigned long long* probes;      // per target, written by k_seed (one atomic per wave)
+  unsigned long long* dfs_probes;  // per target, written by k_dfs
   unsigned long long* fetches;
   // k_dfs workspace geometry (LDS for the fast tier, per-block global for BIG)
   uint32_t hs_cap;      // node-set slots, multiple of 64
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
     a.n_ref[t] = n_ref;
     a.n_nodes[t] = (st == T_OK || st == T_NODE_LIMIT) ? n_ref : 0;
     a.probes[t] = 0;
+    a.dfs_probes[t] = 0;
     a.fetches[t] = 0;
     a.tflag[t] = 0;
     if (t == 0) *a.n_flagged = 0;
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     a.status[t] = st;
     if (st != T_NEEDS_BIG) {     // a large-tier rerun restarts from the seed kernel's counters
       a.n_nodes[t] = n_nodes;
-      a.probes[t] += probes_u;
+      a.dfs_probes[t] = probes_u;
       a.fetches[t] += fetch_u;
     }
   }

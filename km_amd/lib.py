@@ -48,7 +48,8 @@ class Params(C.Structure):
 class BatchSizes(C.Structure):
     _fields_ = [("n_targets", C.c_uint32), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint64),
                 ("n_runs", C.c_uint64), ("logical_probes", C.c_uint64),
-                ("table_fetches", C.c_uint64), ("n_big_tier", C.c_uint32), ("reserved", C.c_uint32)]
+                ("table_fetches", C.c_uint64), ("n_big_tier", C.c_uint32), ("n_flagged", C.c_uint32),
+                ("seed_probes", C.c_uint64)]
 
 
 _P32 = C.POINTER(C.c_uint32)
@@ -269,9 +270,9 @@ class Batch:
         check(self._lib.km_batch_sync(self._b))
 
     def timings(self):
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         check(self._lib.km_batch_timings(self._b, ms))
-        return float(ms[0]), float(ms[1]), float(ms[2])
+        return float(ms[0]), float(ms[1]), float(ms[2]), float(ms[3])
 
     def sizes(self):
         s = BatchSizes()

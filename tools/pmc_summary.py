@@ -1,0 +1,37 @@
+"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (averages per dispatch)
+and derive the HBM traffic of k_seed as MI355X_MICROARCH.md prescribes: read bytes from the
+L2's memory-side request counters by request size (128-B requests are tallied at 64 B by
+FETCH_SIZE on gfx950, so sizes are applied explicitly), write bytes from WRITE_SIZE."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in sorted(glob.glob(root + "/pmc*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kmd::", "")
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for kname, ctrs in agg.items():
+    if not any(x in kname for x in ("k_seed", "k_dfs", "k_graph", "k_pack")):
+        continue
+    out[kname] = {c: sum(v) / len(v) for c, v in ctrs.items()}
+    out[kname]["dispatches"] = len(next(iter(ctrs.values())))
+res = {"per_kernel_avg_per_dispatch": out}
+ks = out.get("k_seed")
+if ks and "TCC_EA0_RDREQ_sum" in ks:
+    r128 = ks.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+    r32 = ks.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    r64 = ks["TCC_EA0_RDREQ_sum"] - r128 - r32
+    rd = r128 * 128 + r64 * 64 + r32 * 32
+    wr = ks.get("WRITE_SIZE", 0.0) * 1024
+    res["k_seed_hbm_read_bytes_per_launch"] = rd
+    res["k_seed_hbm_write_bytes_per_launch"] = wr
+    res["k_seed_hbm_bytes_per_launch"] = rd + wr
+    res["note"] = ("reads = RDREQ_128B*128 + RDREQ_64B*64 + RDREQ_32B*32 (FETCH_SIZE counts every "
+                   "request as 64 B on gfx950 and under-reports by 2x here); writes = WRITE_SIZE KiB")
+json.dump(res, open(sys.argv[2], "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_avg_per_dispatch"}))
