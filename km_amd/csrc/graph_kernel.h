@@ -5,7 +5,8 @@
 // first-index argmin, strict '<' relaxation), :121-198 (two runs, strip reference
 // edges), :200-240 (one source->sink path per remaining edge, unique set).
 //
-// One 64-lane workgroup per target; node numbering as written by the walk kernel,
+// One 256-thread workgroup per target (all four waves share the parallel phases, wave 0
+// runs the short sequential ones); node numbering as written by the walk kernel,
 // BigBang (source) = m, BigCrunch (sink) = m + 1 with m = n_nodes.
 //
 // How the dense O(n^2) algorithm is reproduced exactly on a sparse graph:
@@ -44,6 +45,10 @@
 
 namespace kmd {
 
+constexpr uint32_t GRAPH_THREADS = 256;
+constexpr uint32_t POOL_GROUPS = 64;       // bump-allocation counters, one 128-B line each
+constexpr uint32_t POOL_CTR_STRIDE = 16;   // uint64 per group
+
 struct GraphArgs {
   int k;
   uint64_t kmask;
@@ -60,8 +65,11 @@ struct GraphArgs {
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
   uint32_t* t_pathbase;      // per target: first path record
-  unsigned long long* counters;  // [0] paths used, [1] runs used, [2] overflow flag
-  uint64_t path_pool, run_pool;  // capacities
+  // Pools are split into POOL_GROUPS equal regions (group = target & 63) so that the
+  // bump-allocation atomics of different targets rarely share an address.
+  // counters[g*16+0] paths used in group g, [g*16+1] runs used, counters[64*16] overflow flag
+  unsigned long long* counters;
+  uint64_t path_pool, run_pool;  // total capacities (multiples of POOL_GROUPS)
   uint32_t* p_target;
   uint64_t* p_runbase;
   uint32_t* p_nruns;
@@ -97,16 +105,27 @@ __host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap)
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
+__global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
   using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
   constexpr idx_t NONE = (idx_t)~(idx_t)0;
   constexpr uint32_t NIL = 0xFFFFFFFFu;
   extern __shared__ __align__(16) unsigned char smem[];
-  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t tid = threadIdx.x, NT = GRAPH_THREADS;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t t = a.tids ? a.tids[blockIdx.x] : blockIdx.x;
+  // wave-local ordering for the sections only wave 0 executes
+  auto wsync = [&]() {
+    if constexpr (BIG) __threadfence_block();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // bump allocation in this target's pool group
+  const uint32_t pg = t % POOL_GROUPS;
+  const uint64_t pg_paths = a.path_pool / POOL_GROUPS, pg_runs = a.run_pool / POOL_GROUPS;
+  unsigned long long* ctr = a.counters + (uint64_t)pg * POOL_CTR_STRIDE;
+  unsigned long long* ovf = a.counters + (uint64_t)POOL_GROUPS * POOL_CTR_STRIDE;
 
   if (a.status[t] != T_OK) {
-    if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
   const uint32_t m = a.n_nodes[t];
@@ -114,7 +133,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   const uint32_t n = m + 2, src = m, snk = m + 1;
   const uint32_t ncap = a.ncap, hcap = a.hcap;
   if (n > ncap || (uint64_t)3 * n > (uint64_t)2 * hcap || (!BIG && n >= 0xFFFFu)) {
-    if (lane == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
   const uint64_t nb = a.node_base[t];
@@ -162,13 +181,13 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     const uint64_t fill_bytes = graph_region_a<idx_t>(ncap, hcap) + ((((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull);
     uint4* q = reinterpret_cast<uint4*>(wsb);
     const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    for (uint64_t x = lane; x < fill_bytes / 16; x += 64) q[x] = ones;
+    for (uint64_t x = tid; x < fill_bytes / 16; x += NT) q[x] = ones;
   }
-  for (uint32_t w = lane; w < nbw; w += 64) { link[w] = 0; inq[w] = 0; }
-  for (uint32_t w = lane; w < n_removed_words; w += 64) removed[w] = 0;
-  if (lane < 8) scal[lane] = 0;
+  for (uint32_t w = tid; w < nbw; w += NT) { link[w] = 0; inq[w] = 0; }
+  for (uint32_t w = tid; w < n_removed_words; w += NT) removed[w] = 0;
+  if (tid < 8) scal[tid] = 0;
   __syncthreads();
-  for (uint32_t j = lane; j < m; j += 64) {
+  for (uint32_t j = tid; j < m; j += NT) {
     const uint64_t X = nk[j];
     bool wn;
     const int s = set_insert_lane(pkeys, hcap, X >> 2, &wn);
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   // two nodes does not find its own index there
   {
     uint32_t dup = 0;
-    for (uint32_t j = lane; j < m; j += 64) {
+    for (uint32_t j = tid; j < m; j += NT) {
       const uint64_t X = nk[j];
       const uint64_t P = X >> 2;
       uint32_t s = set_home(P, hcap);
@@ -192,14 +211,14 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
       }
       if (got != (idx_t)j) dup = 1;
     }
-    if (__any((int)dup)) {
-      if (lane == 0) { a.status[t] = T_REPEAT; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (__syncthreads_or((int)dup)) {
+      if (tid == 0) { a.status[t] = T_REPEAT; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
       return;
     }
   }
-  if (a.dbg == 1) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 1) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 2. adjacency: succ[4j+c] = node of kmer[j][1:]+c ; pred[4v+f] = j, f = first base of j
-  for (uint32_t j = lane; j < m; j += 64) {
+  for (uint32_t j = tid; j < m; j += NT) {
     const uint64_t X = nk[j];
     const uint64_t S = X & a.pmask;
     const uint32_t fb = (uint32_t)(X >> (2 * (k - 1))) & 3u;
@@ -221,9 +240,9 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     }
   }
   __syncthreads();
-  if (a.dbg == 2) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 2) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 2b. link[j]: j -> j+1 is j's only out-edge and j+1's only in-edge ---------------
-  for (uint32_t base = 0; base < m; base += 64) {
+  for (uint32_t base = wave * 64; base < m; base += NT) {
     const uint32_t j = base + lane;
     bool lk = false;
     if (j + 1 < m && j != n_ref - 1) {                            // n_ref-1 also feeds the sink
@@ -269,33 +288,37 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   // stripped, and edges (source,0) and (0,1) both generate the one path 0..n_ref-1.
   if (m == n_ref && a.dbg == 0) {
     bool pure = (n_ref == 1) || (chain_head(n_ref - 1) == 0);
-    if (lane < 4) pure = pure && (succ[4 * (n_ref - 1) + lane] == NONE) && (pred[lane] == NONE);
-    if (__all((int)pure)) {
-      uint32_t mincov = 0xFFFFFFFFu;
-      for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
-      for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
-      if (lane == 0) {
-        const unsigned long long pi = atomicAdd(&a.counters[0], 1ull);
-        const unsigned long long ri = atomicAdd(&a.counters[1], 1ull);
-        if (pi + 1 > a.path_pool || ri + 1 > a.run_pool) {
-          atomicExch(&a.counters[2], 1ull);
-          a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
-        } else {
-          a.r_start[ri] = 0; a.r_len[ri] = n_ref;
-          a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
-          a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
+    if (tid < 4) pure = pure && (succ[4 * (n_ref - 1) + tid] == NONE) && (pred[tid] == NONE);
+    if (__syncthreads_and((int)pure)) {
+      if (wave == 0) {
+        uint32_t mincov = 0xFFFFFFFFu;
+        for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
+        if (lane == 0) {
+          const unsigned long long pl = atomicAdd(&ctr[0], 1ull);
+          const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
+          if (pl + 1 > pg_paths || rl + 1 > pg_runs) {
+            atomicExch(ovf, 1ull);
+            a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
+          } else {
+            const uint64_t pi = (uint64_t)pg * pg_paths + pl, ri = (uint64_t)pg * pg_runs + rl;
+            a.r_start[ri] = 0; a.r_len[ri] = n_ref;
+            a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
+            a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
+          }
+          a.g_status[t] = T_OK;
         }
-        a.g_status[t] = T_OK;
       }
       return;
     }
   }
 
-  for (uint32_t j = lane; j < n; j += 64) { dist_f[j] = INF; dist_b[j] = INF; }
+  for (uint32_t j = tid; j < n; j += NT) { dist_f[j] = INF; dist_b[j] = INF; }
   __syncthreads();
 
-  if (a.dbg == 3) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 3) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 3. exact distances -------------------------------------------------------------
+  if (wave == 0) {
   for (int dir = 0; dir < 2; ++dir) {
     float* dist = dir ? dist_b : dist_f;
     const idx_t* adj = dir ? pred : succ;
@@ -304,7 +327,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     float d = 0.0f + W_REF;                                         // cap edge from the root
     if (dir == 1) { for (uint32_t w = lane; w < nbw; w += 64) inq[w] = 0; }
     if (lane == 0) { dist[dir ? snk : src] = 0.0f; dist[cur] = d; }
-    __syncthreads();
+    wsync();
     uint32_t guard = 0;
     while (guard++ <= n) {
       // (cur, d) is final: run along its chain in registers
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
         atomicOr(&inq[v >> 5], 1u << (v & 31));
       }
       fcount += (uint32_t)__popcll(pm);
-      __syncthreads();
+      wsync();
       if (fcount == 0) break;
       // extract the frontier entry with the smallest distance
       uint32_t pos = 0;
@@ -396,16 +419,18 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
       }
       cur = frontier[pos];
       d = dist[cur];
-      __syncthreads();
+      wsync();
       if (lane == 0) frontier[pos] = frontier[fcount - 1];
       --fcount;
-      __syncthreads();
+      wsync();
     }
   }
+  }   // wave 0
+  __syncthreads();
 
-  if (a.dbg == 4) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 4) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 4. predecessor arrays by the local rule ------------------------------------
-  for (uint32_t j = lane; j < n; j += 64) {
+  for (uint32_t j = tid; j < n; j += NT) {
     {
       idx_t best = NONE;
       float bv = INF, bd = INF;
@@ -462,23 +487,23 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   };
   auto is_removed = [&](uint32_t e) -> bool { return (removed[e >> 5] >> (e & 31)) & 1u; };
 
-  if (a.dbg == 5) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 5) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 5. strip reference edges (Graph.py:184-197) ---------------------------------
   // curs = nodes whose predecessor is the source; only node 0 has an edge from it.
   if (before[0] == (idx_t)src) {
     // common case: the sink-tree chain from node 0 is 0,1,...,n_ref-1,sink
     bool ok = true;
-    for (uint32_t i = lane; i < n_ref; i += 64) {
+    for (uint32_t i = tid; i < n_ref; i += NT) {
       const uint32_t want = (i + 1 < n_ref) ? i + 1 : snk;
       if (after[i] != (idx_t)want) ok = false;
     }
-    if (__all((int)ok)) {
-      for (uint32_t i = 1 + lane; i < n_ref; i += 64) {      // first edge (0 -> 1) is kept
+    if (__syncthreads_and((int)ok)) {
+      for (uint32_t i = 1 + tid; i < n_ref; i += NT) {       // first edge (0 -> 1) is kept
         const uint32_t e = edge_id(i, (i + 1 < n_ref) ? i + 1 : snk);
         if (e != NIL) atomicOr(&removed[e >> 5], 1u << (e & 31));
       }
     } else {
-      if (lane == 0) {
+      if (tid == 0) {
         uint32_t cur = 0, last = NIL, hops = 0;
         while (after[cur] != NONE && hops++ <= n) {
           cur = after[cur];
@@ -493,10 +518,10 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   }
   __syncthreads();
 
-  if (a.dbg == 6) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 6) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 6. candidate edges and their unique representatives --------------------------
   const uint32_t n_edges = 4 * m + 2;
-  for (uint32_t e = lane; e < n_edges; e += 64) {
+  for (uint32_t e = tid; e < n_edges; e += NT) {
     uint32_t ea, eb;
     bool exists;
     if (e == 4 * m) { ea = src; eb = 0; exists = true; }
@@ -522,11 +547,11 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
   __syncthreads();
   const uint32_t n_cand = scal[0];
   if (n_cand > ccap) {
-    if (lane == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
 
-  if (a.dbg == 7) { if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 7) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 7. emit paths (caps stripped) as runs of consecutive node indices -------------
   // A path is walked chain by chain (wave-uniform): backwards from `a` along before[]
   // — inside a chain before[j] == j-1 — then forwards from `b` along after[].  Runs
@@ -599,23 +624,27 @@ __global__ __launch_bounds__(64) void k_graph(GraphArgs a) {
     return total;
   };
 
+  if (wave != 0) return;                 // emission is wave-uniform work for one wave
   // pass 1: count runs per path
   uint32_t total_runs = 0;
   for (uint32_t p = 0; p < n_cand; ++p)
     total_runs += walk_path(cand[2 * p], cand[2 * p + 1], [](uint32_t, uint32_t, uint32_t) {});
   unsigned long long run_base = 0, path_base = 0;
+  unsigned long long over = 0;
   if (lane == 0) {
-    path_base = atomicAdd(&a.counters[0], (unsigned long long)n_cand);
-    run_base = atomicAdd(&a.counters[1], (unsigned long long)total_runs);
-    if (path_base + n_cand > a.path_pool || run_base + total_runs > a.run_pool) {
-      atomicExch(&a.counters[2], 1ull);
-      scal[1] = 1;
+    path_base = atomicAdd(&ctr[0], (unsigned long long)n_cand);
+    run_base = atomicAdd(&ctr[1], (unsigned long long)total_runs);
+    if (path_base + n_cand > pg_paths || run_base + total_runs > pg_runs) {
+      atomicExch(ovf, 1ull);
+      over = 1;
     }
+    path_base += (uint64_t)pg * pg_paths;
+    run_base += (uint64_t)pg * pg_runs;
   }
   path_base = __shfl(path_base, 0);
   run_base = __shfl(run_base, 0);
-  __syncthreads();
-  if (scal[1]) {        // pools exhausted: host enlarges them and reruns the stage
+  over = __shfl(over, 0);
+  if (over) {        // pools exhausted: host enlarges them and reruns the stage
     if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }

@@ -394,7 +394,7 @@ struct km_batch {
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
   std::vector<uint64_t> h_probes, h_fetches;
   std::vector<unsigned long long> h_dfs_probes;
-  unsigned long long h_counters[4] = {0, 0, 0, 0};
+  unsigned long long h_overflow = 0;
   uint32_t n_big = 0;
   // geometry of the last launch
   bool fast_ok = true;
@@ -447,9 +447,9 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA;
   A(b->d_node_kmer.alloc(pool));
   A(b->d_node_cnt.alloc(pool));
-  A(b->d_counters.alloc(4));
-  b->path_pool = (uint64_t)max_targets * 4 + 4096;
-  b->run_pool = (uint64_t)max_targets * 16 + 16384;
+  A(b->d_counters.alloc(POOL_GROUPS * POOL_CTR_STRIDE + 16));
+  b->path_pool = (((uint64_t)max_targets * 4 + 8192) / POOL_GROUPS + 1) * POOL_GROUPS;
+  b->run_pool = (((uint64_t)max_targets * 16 + 32768) / POOL_GROUPS + 1) * POOL_GROUPS;
   A(b->d_p_target.alloc(b->path_pool));
   A(b->d_p_runbase.alloc(b->path_pool));
   A(b->d_p_nruns.alloc(b->path_pool));
@@ -649,9 +649,9 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
 }
 
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
-  HIPCHK(hipMemsetAsync(b->d_counters.p, 0, 4 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
   if (b->fast_ok) {
-    hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(64), b->graph_lds, st, b->ga);
+    hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, b->ga);
   } else {
     // no LDS-resident tier for these parameters: mark everything for the large tier
     HIPCHK(hipMemsetAsync(b->d_gstatus.p, 0, (uint64_t)b->n_targets * 4, st));
@@ -743,7 +743,7 @@ static int pull_status(km_batch* b, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(b->h_gstatus.data(), b->d_gstatus.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_npaths.data(), b->d_npaths.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_pathbase.data(), b->d_pathbase.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(b->h_counters, b->d_counters.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&b->h_overflow, b->d_counters.p + POOL_GROUPS * POOL_CTR_STRIDE, 8, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(hipStreamSynchronize(st));
   b->h_seed_probes = 0;
@@ -845,7 +845,7 @@ static int run_big_graph(km_batch* b, const std::vector<uint32_t>& ids, hipStrea
   for (uint32_t s = 0; s < nb; s += per) {
     const uint32_t cnt = std::min(per, nb - s);
     g.tids = b->d_big_ids.p + s;
-    hipLaunchKernelGGL(k_graph<true>, dim3(cnt), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_graph<true>, dim3(cnt), dim3(GRAPH_THREADS), 0, st, g);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -853,8 +853,8 @@ static int run_big_graph(km_batch* b, const std::vector<uint32_t>& ids, hipStrea
 }
 
 static int grow_path_pools(km_batch* b) {
-  b->path_pool *= 4;
-  b->run_pool *= 4;
+  b->path_pool = (b->path_pool * 4 / POOL_GROUPS + 1) * POOL_GROUPS;
+  b->run_pool = (b->run_pool * 4 / POOL_GROUPS + 1) * POOL_GROUPS;
   int rc = KM_OK;
   auto A = [&](int r) { if (rc == KM_OK) rc = r; };
   A(b->d_p_target.alloc(b->path_pool)); A(b->d_p_runbase.alloc(b->path_pool));
@@ -936,7 +936,7 @@ extern "C" int km_batch_sync(km_batch_t* b) {
         rc = pull_status(b, st);
         if (rc != KM_OK) return rc;
       }
-      if (!b->h_counters[2]) break;
+      if (!b->h_overflow) break;
     }
   }
   b->synced = true;
@@ -972,7 +972,7 @@ extern "C" int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* s) {
   s->n_paths = (uint32_t)paths;
   // runs: sum over the path records actually referenced
   if (b->ran_graph && paths) {
-    std::vector<uint32_t> nruns((size_t)b->h_counters[0]);
+    std::vector<uint32_t> nruns((size_t)b->path_pool);
     HIPCHK(hipMemcpy(nruns.data(), b->d_p_nruns.p, nruns.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t t = 0; t < b->n_targets; ++t)
       for (uint32_t i = 0; i < b->h_npaths[t]; ++i) s->n_runs += nruns[b->h_pathbase[t] + i];
@@ -1042,7 +1042,7 @@ extern "C" int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out) {
   // ---- paths
   if (b->ran_graph && (out->path_off || out->run_off || out->run_start || out->run_len ||
                        out->path_len || out->path_min_cov)) {
-    const uint64_t np = b->h_counters[0], nr = b->h_counters[1];
+    const uint64_t np = b->path_pool, nr = b->run_pool;
     std::vector<uint32_t> p_nruns(np), p_len(np), p_mincov(np), r_start(nr), r_len(nr);
     std::vector<uint64_t> p_runbase(np);
     if (np) {
