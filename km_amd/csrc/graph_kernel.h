@@ -175,29 +175,88 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
   };
 
   // ---- 1. prefix table: (k-1)-mer prefix -> node index per last base -----------------
-  // EMPTY keys and NONE indices are all-ones bytes: one wide fill covers the prefix table
-  // (region A) and succ / pred that follow it
+  // EMPTY keys and NONE indices are all-ones bytes.  First only the key array is filled:
+  // inserting the prefixes already tells whether the graph is a bare reference chain.
+  const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
   {
-    const uint64_t fill_bytes = graph_region_a<idx_t>(ncap, hcap) + ((((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull);
     uint4* q = reinterpret_cast<uint4*>(wsb);
-    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    for (uint64_t x = tid; x < fill_bytes / 16; x += NT) q[x] = ones;
+    for (uint64_t x = tid; x < (uint64_t)hcap / 2; x += NT) q[x] = ones;      // hcap keys, 8 B each
   }
   for (uint32_t w = tid; w < nbw; w += NT) { link[w] = 0; inq[w] = 0; }
   for (uint32_t w = tid; w < n_removed_words; w += NT) removed[w] = 0;
   if (tid < 8) scal[tid] = 0;
   __syncthreads();
+  uint32_t shared_prefix = 0;            // some other node has the same (k-1)-mer prefix
   for (uint32_t j = tid; j < m; j += NT) {
-    const uint64_t X = nk[j];
     bool wn;
-    const int s = set_insert_lane(pkeys, hcap, X >> 2, &wn);
-    if (s >= 0) pidx[4 * s + (uint32_t)(X & 3)] = (idx_t)j;
+    const int s = set_insert_lane(pkeys, hcap, nk[j] >> 2, &wn);
+    if (s < 0 || !wn) shared_prefix = 1;
   }
   __syncthreads();
-  // a k-mer present twice (km/utils/common.py:55-59) shares one table entry: one of the
-  // two nodes does not find its own index there
+
+  // ---- 1b. the common case: nothing but the reference chain ---------------------------
+  // m == n_ref, all prefixes distinct and the suffix of the last k-mer is not a prefix:
+  // node j's only overlap edge goes to j+1 and nothing else exists (no duplicate k-mer
+  // either).  Then both Dijkstra trees are the chain, every reference edge but the first
+  // is stripped, and edges (source,0) and (0,1) both generate the one path 0..n_ref-1.
+  {
+    uint32_t not_pure = shared_prefix | (m != n_ref ? 1u : 0u) | (a.dbg != 0 ? 1u : 0u);
+    if (tid == 0 && !not_pure) {
+      const uint64_t S = nk[m - 1] & a.pmask;
+      uint32_t s = set_home(S, hcap);
+      for (uint32_t step = 0; step < hcap; ++step) {
+        const uint64_t kv = pkeys[s];
+        if (kv == S) { not_pure = 1; break; }
+        if (kv == EMPTY) break;
+        if (++s == hcap) s = 0;
+      }
+    }
+    if (!__syncthreads_or((int)not_pure)) {
+      if (wave == 0) {
+        uint32_t mincov = 0xFFFFFFFFu;
+        for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
+        if (lane == 0) {
+          const unsigned long long pl = atomicAdd(&ctr[0], 1ull);
+          const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
+          if (pl + 1 > pg_paths || rl + 1 > pg_runs) {
+            atomicExch(ovf, 1ull);
+            a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
+          } else {
+            const uint64_t pi = (uint64_t)pg * pg_paths + pl, ri = (uint64_t)pg * pg_runs + rl;
+            a.r_start[ri] = 0; a.r_len[ri] = n_ref;
+            a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
+            a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
+          }
+          a.g_status[t] = T_OK;
+        }
+      }
+      return;
+    }
+  }
+
+  // ---- 1c. general case: node index per (prefix, last base); succ / pred start empty ----
+  {
+    const uint64_t fill_bytes = graph_region_a<idx_t>(ncap, hcap) + ((((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull);
+    uint4* q = reinterpret_cast<uint4*>(wsb);
+    for (uint64_t x = (uint64_t)hcap / 2 + tid; x < fill_bytes / 16; x += NT) q[x] = ones;
+  }
+  __syncthreads();
   {
     uint32_t dup = 0;
+    for (uint32_t j = tid; j < m; j += NT) {
+      const uint64_t X = nk[j];
+      const uint64_t P = X >> 2;
+      uint32_t s = set_home(P, hcap);
+      for (uint32_t step = 0; step < hcap; ++step) {
+        if (pkeys[s] == P) break;
+        if (++s == hcap) s = 0;
+      }
+      pidx[4 * s + (uint32_t)(X & 3)] = (idx_t)j;
+    }
+    __syncthreads();
+    // a k-mer present twice (km/utils/common.py:55-59) shares one table entry: one of the
+    // two nodes does not find its own index there
     for (uint32_t j = tid; j < m; j += NT) {
       const uint64_t X = nk[j];
       const uint64_t P = X >> 2;
@@ -281,37 +340,6 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
     }
     return s;
   };
-
-  // ---- 2c. the common case: nothing but the reference chain -------------------------
-  // m == n_ref, node j's only edge goes to j+1, nothing enters node 0 or leaves the last
-  // node.  Then both Dijkstra trees are the chain, every reference edge but the first is
-  // stripped, and edges (source,0) and (0,1) both generate the one path 0..n_ref-1.
-  if (m == n_ref && a.dbg == 0) {
-    bool pure = (n_ref == 1) || (chain_head(n_ref - 1) == 0);
-    if (tid < 4) pure = pure && (succ[4 * (n_ref - 1) + tid] == NONE) && (pred[tid] == NONE);
-    if (__syncthreads_and((int)pure)) {
-      if (wave == 0) {
-        uint32_t mincov = 0xFFFFFFFFu;
-        for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
-        if (lane == 0) {
-          const unsigned long long pl = atomicAdd(&ctr[0], 1ull);
-          const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
-          if (pl + 1 > pg_paths || rl + 1 > pg_runs) {
-            atomicExch(ovf, 1ull);
-            a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
-          } else {
-            const uint64_t pi = (uint64_t)pg * pg_paths + pl, ri = (uint64_t)pg * pg_runs + rl;
-            a.r_start[ri] = 0; a.r_len[ri] = n_ref;
-            a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
-            a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
-          }
-          a.g_status[t] = T_OK;
-        }
-      }
-      return;
-    }
-  }
 
   for (uint32_t j = tid; j < n; j += NT) { dist_f[j] = INF; dist_b[j] = INF; }
   __syncthreads();
