@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify a sample against the oracle")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="replay each step as one captured hipGraph (measured: no gain, GPU-bound)")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,26 +136,39 @@ def main():
     # ---- this rank's shard of targets, resident in HBM -----------------------------------
     mine = bases_all[rank * T:(rank + 1) * T].contiguous()
     offsets = (np.arange(T + 1, dtype=np.uint64) * np.uint64(args.length))
-    batch = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
-                        max_targets=T, max_total_bases=T * args.length)
-    batch.set_targets_dev(mine.data_ptr(), offsets, stream)
+    # `inflight` independent workspaces, each with its own HIP stream: while one batch is in
+    # its latency-bound kernels (k_dfs, k_graph) the next one runs its HBM-bound k_seed
+    n_fl = max(1, args.inflight)
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(n_fl)]
+    batches = []
+    for q in range(n_fl):
+        bq = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
+                         max_targets=T, max_total_bases=T * args.length)
+        bq.set_targets_dev(mine.data_ptr(), offsets, stream)
+        batches.append(bq)
+    torch.cuda.synchronize()
+    batch = batches[0]
     both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    replay = (both | kmlib.KM_RUN_HIPGRAPH) if args.hipgraph else both
 
     # ---- warm-up ---------------------------------------------------------------------------
-    for _ in range(max(1, args.warmup)):
-        batch.run(both, stream)
-    batch.sync()
+    for i in range(max(1, args.warmup)):
+        for q in range(n_fl):
+            batches[q].run(replay, tstreams[q].cuda_stream)
+    for bq in batches:
+        bq.sync()
     sizes = batch.sizes()
     probes_per_step = int(sizes.logical_probes)
     fetches_per_step = int(sizes.table_fetches)
 
-    # ---- timed region: exactly K steps ----------------------------------------------------
+    # ---- timed region: exactly K steps (one step = one pass over one batch) ---------------
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run(both, stream)
+    for i in range(args.steps):
+        q = i % n_fl
+        batches[q].run(replay, tstreams[q].cuda_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -160,6 +177,16 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    for bq in batches:
+        bq.sync()
+
+    # ---- latency of one isolated step (no pipelining) --------------------------------------
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        batch.run(both, stream)
+    torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
     batch.sync()
 
     # ---- per-kernel durations (HIP events on the launch stream), averaged over K launches
@@ -233,6 +260,9 @@ def main():
             "logical_probes_per_step": probes_per_step,
             "table_fetches_per_step": fetches_per_step,
             "kernel_ms": {"walk": walk_avg, "k_seed": seed_avg, "graph": graph_avg},
+            "batches_in_flight": n_fl,
+            "hipgraph_replay": bool(args.hipgraph),
+            "ms_per_step_unpipelined": serial_ms,
             "result_fetch_ms": fetch_s * 1e3,
             "setup_s": {"generate": t_gen, "h2d_broadcast": t_bcast, "table_build": t_build},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved,

@@ -172,6 +172,10 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
                              uint32_t n_targets, void* stream);
 #define KM_STAGE_WALK  1
 #define KM_STAGE_GRAPH 2
+/* OR into `stages`: capture the step into a hipGraph on first use and replay it with one
+ * launch afterwards (until the targets change).  Per-kernel HIP-event timings are not
+ * available for replayed steps. */
+#define KM_RUN_HIPGRAPH 4
 /* Launch the kernels asynchronously on `stream` (no host synchronisation unless
  * a target overflows the fast tier, in which case the large-tier pass needs one). */
 int km_batch_run(km_batch_t* b, int stages, void* stream);
@@ -187,6 +191,9 @@ int km_batch_timings(km_batch_t* b, float* ms4);
 const char* km_strerror(int code);
 const char* km_last_error(void);   /* thread-local detail of the last failure */
 int km_device_count(int* n);
+/* A non-blocking HIP stream on `device` for callers that do not bring their own. */
+int km_stream_create(int device, void** stream);
+int km_stream_destroy(void* stream);
 const char* km_version(void);
 
 #ifdef __cplusplus

@@ -61,6 +61,10 @@ struct GraphArgs {
   const uint32_t* n_nodes;
   const uint32_t* n_ref;
   uint32_t* status;          // T_REPEAT is raised here (duplicate k-mer in the target)
+  const uint32_t* tflag;     // target has flagged seeds (its node list comes from k_dfs)
+  uint32_t* need_full;       // k_graph_pure -> k_graph: target needs the general algorithm
+  uint32_t use_need_full;    // k_graph: skip targets k_graph_pure already answered
+  uint32_t hcap_pure;        // k_graph_pure: prefix-key slots (multiple of 64)
   // outputs
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
@@ -104,6 +108,84 @@ __host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap)
   return (b + 15) & ~15ull;
 }
 
+
+// ---------------------------------------------------------------------------- k_graph_pure
+// Unflagged targets (node list == the target's own k-mers, final right after k_seed):
+// decide whether the graph is the bare reference chain — all (k-1)-mer prefixes distinct
+// and the last k-mer's suffix not among them — and if so emit its single path.  Small LDS
+// (prefix keys only), so it runs at full occupancy and overlaps k_dfs on a second stream.
+// Everything else is left to k_graph through need_full[].
+__global__ __launch_bounds__(GRAPH_THREADS) void k_graph_pure(GraphArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, NT = GRAPH_THREADS;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const uint32_t t = blockIdx.x;
+  if (a.status[t] != T_OK) {
+    if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    return;
+  }
+  if (a.tflag[t]) return;                      // k_graph handles it once k_dfs is done
+  const uint32_t n_ref = a.n_ref[t];
+  const uint32_t hcap = a.hcap_pure;
+  if ((uint64_t)3 * (n_ref + 2) > (uint64_t)2 * hcap || a.dbg != 0) {
+    if (tid == 0) a.need_full[t] = 1;
+    return;
+  }
+  const uint64_t nb = a.node_base[t];
+  const uint64_t* nk = a.node_kmer + nb;
+  const uint32_t* ncnt = a.node_cnt + nb;
+  uint64_t* pkeys = reinterpret_cast<uint64_t*>(smem);
+  {
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint4* q = reinterpret_cast<uint4*>(smem);
+    for (uint32_t x = tid; x < hcap / 2; x += NT) q[x] = ones;
+  }
+  __syncthreads();
+  uint32_t not_pure = 0;
+  for (uint32_t j = tid; j < n_ref; j += NT) {
+    bool wn;
+    const int s = set_insert_lane(pkeys, hcap, nk[j] >> 2, &wn);
+    if (s < 0 || !wn) not_pure = 1;
+  }
+  __syncthreads();
+  if (tid == 0 && !not_pure) {
+    const uint64_t S = nk[n_ref - 1] & a.pmask;
+    uint32_t s = set_home(S, hcap);
+    for (uint32_t step = 0; step < hcap; ++step) {
+      const uint64_t kv = pkeys[s];
+      if (kv == S) { not_pure = 1; break; }
+      if (kv == EMPTY) break;
+      if (++s == hcap) s = 0;
+    }
+  }
+  if (__syncthreads_or((int)not_pure)) {
+    if (tid == 0) a.need_full[t] = 1;
+    return;
+  }
+  if (wave != 0) return;
+  uint32_t mincov = 0xFFFFFFFFu;
+  for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
+  if (lane == 0) {
+    const uint32_t pg = t % POOL_GROUPS;
+    const uint64_t pg_paths = a.path_pool / POOL_GROUPS, pg_runs = a.run_pool / POOL_GROUPS;
+    unsigned long long* ctr = a.counters + (uint64_t)pg * POOL_CTR_STRIDE;
+    const unsigned long long pl = atomicAdd(&ctr[0], 1ull);
+    const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
+    if (pl + 1 > pg_paths || rl + 1 > pg_runs) {
+      atomicExch(a.counters + (uint64_t)POOL_GROUPS * POOL_CTR_STRIDE, 1ull);
+      a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
+    } else {
+      const uint64_t pi = (uint64_t)pg * pg_paths + pl, ri = (uint64_t)pg * pg_runs + rl;
+      a.r_start[ri] = 0; a.r_len[ri] = n_ref;
+      a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
+      a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
+    }
+    a.need_full[t] = 0;
+    a.g_status[t] = T_OK;
+  }
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
   using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
@@ -128,6 +210,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
     if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
+  if (a.use_need_full && !a.tflag[t] && !a.need_full[t]) return;   // answered by k_graph_pure
   const uint32_t m = a.n_nodes[t];
   const uint32_t n_ref = a.n_ref[t];
   const uint32_t n = m + 2, src = m, snk = m + 1;

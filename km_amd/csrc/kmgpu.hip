@@ -63,6 +63,19 @@ extern "C" int km_device_count(int* n) {
   return KM_OK;
 }
 
+extern "C" int km_stream_create(int device, void** stream) {
+  if (!stream) return fail(KM_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = st;
+  return KM_OK;
+}
+extern "C" int km_stream_destroy(void* stream) {
+  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return KM_OK;
+}
+
 // ------------------------------------------------------------------------ database
 struct kmjf {
   int k = 0;
@@ -336,7 +349,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-constexpr uint32_t FAST_EXTRA = 256;          // walk-discovered nodes a fast-tier target may add
+constexpr uint32_t FAST_EXTRA = 192;          // walk-discovered nodes a fast-tier target may add
 constexpr uint32_t FAST_LDS_LIMIT = 64 * 1024;
 
 }  // namespace
@@ -374,7 +387,16 @@ struct km_batch {
   DevBuf<uint32_t> d_node_cap;
   std::vector<uint64_t> h_node_base;
   std::vector<uint32_t> h_node_cap;
-  DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase;
+  DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full;
+  hipStream_t side = nullptr;          // overlaps k_graph_pure with k_dfs
+  hipEvent_t ev_seed_done = nullptr, ev_pure_done = nullptr;       // eager fork / join
+  hipEvent_t ev_cap_seed = nullptr, ev_cap_pure = nullptr;         // fork / join inside a captured step
+  uint32_t pure_lds = 0;
+  bool timed = false;                  // the last run recorded its timing events
+  hipGraph_t graph = nullptr;          // captured step (KM_RUN_HIPGRAPH)
+  hipGraphExec_t gexec = nullptr;
+  int graph_stages = 0;
+  hipStream_t graph_stream = nullptr;
   DevBuf<uint64_t> d_probes, d_fetches;
   // node pools
   DevBuf<uint64_t> d_node_kmer;
@@ -442,6 +464,7 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_gstatus.alloc(max_targets));
   A(b->d_npaths.alloc(max_targets));
   A(b->d_pathbase.alloc(max_targets));
+  A(b->d_need_full.alloc(max_targets));
   A(b->d_probes.alloc(max_targets));
   A(b->d_fetches.alloc(max_targets));
   const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA;
@@ -458,6 +481,14 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_r_start.alloc(b->run_pool));
   A(b->d_r_len.alloc(b->run_pool));
   if (rc == KM_OK) {
+    if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_seed_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_pure_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_cap_seed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_cap_pure, hipEventDisableTiming) != hipSuccess)
+      rc = fail(KM_E_HIP, "stream/event creation failed");
+  }
+  if (rc == KM_OK) {
     for (int i = 0; i < 5; ++i)
       if (hipEventCreate(&b->ev[i]) != hipSuccess) rc = fail(KM_E_HIP, "hipEventCreate failed");
   }
@@ -466,15 +497,28 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   return KM_OK;
 }
 
+static void drop_graph(km_batch* b) {
+  if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
+  b->gexec = nullptr;
+  b->graph = nullptr;
+}
+
 extern "C" int km_batch_destroy(km_batch_t* b) {
   if (!b) return KM_OK;
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
+  drop_graph(b);
   b->d_bases.release(); b->d_toff.release(); b->d_woff.release(); b->d_packed.release();
   b->d_items.release(); b->d_item_off.release(); b->d_flagbits.release(); b->d_fw_off.release();
   b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_dfs_probes.release(); b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
-  b->d_npaths.release(); b->d_pathbase.release(); b->d_probes.release(); b->d_fetches.release();
+  b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release();
+  if (b->side) (void)hipStreamDestroy(b->side);
+  if (b->ev_seed_done) (void)hipEventDestroy(b->ev_seed_done);
+  if (b->ev_pure_done) (void)hipEventDestroy(b->ev_pure_done);
+  if (b->ev_cap_seed) (void)hipEventDestroy(b->ev_cap_seed);
+  if (b->ev_cap_pure) (void)hipEventDestroy(b->ev_cap_pure); b->d_probes.release(); b->d_fetches.release();
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
@@ -525,6 +569,7 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
 
 static int push_layout(km_batch* b, hipStream_t st) {
   const uint32_t n = b->n_targets;
+  drop_graph(b);                       // geometry and pointers may change with the targets
   {
     // tref[j] = distance of reference node j from the source along the reference chain,
     // accumulated exactly as Graph.py does: float32 0 + 0.01f, then + 0.01f per hop
@@ -626,6 +671,10 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.n_nodes = b->d_n_nodes.p;
   g.n_ref = b->d_n_ref.p;
   g.status = b->d_status.p;
+  g.tflag = b->d_tflag.p;
+  g.need_full = b->d_need_full.p;
+  g.use_need_full = 0;
+  g.hcap_pure = 0;
   g.g_status = b->d_gstatus.p;
   g.t_npaths = b->d_npaths.p;
   g.t_pathbase = b->d_pathbase.p;
@@ -648,9 +697,20 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   if (b->graph_mode == 1) g.dbg = 1;       // duplicate check only
 }
 
+static void pure_geometry(km_batch* b) {
+  const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
+  b->ga.hcap_pure = round_up((max_nref + 2) + (max_nref + 2) / 2 + 1, 64);
+  b->pure_lds = b->ga.hcap_pure * 8;
+  if (b->pure_lds > FAST_LDS_LIMIT) { b->ga.hcap_pure = 64; b->pure_lds = 512; }   // all -> need_full
+}
+
+// Graph stage on one stream: pure-chain pass, then the general kernel for the rest.
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
   if (b->fast_ok) {
+    pure_geometry(b);
+    b->ga.use_need_full = 1;
+    hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(GRAPH_THREADS), b->pure_lds, st, b->ga);
     hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, b->ga);
   } else {
     // no LDS-resident tier for these parameters: mark everything for the large tier
@@ -667,6 +727,17 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = (hipStream_t)stream;
   b->last_stream = st;
+  const bool want_graph = (stages & KM_RUN_HIPGRAPH) != 0;
+  stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
+  if (want_graph && b->gexec && b->graph_stages == stages && b->graph_stream == st) {
+    HIPCHK(hipGraphLaunch(b->gexec, st));
+    b->ran_walk = true;
+    b->ran_graph = true;
+    b->big_walk_done = false;
+    b->synced = false;
+    b->timed = false;
+    return KM_OK;
+  }
   const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
 
   // ---- fast-tier geometry
@@ -694,36 +765,71 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   b->walk_lds = (uint32_t)wl;
   b->graph_lds = (uint32_t)gl;
 
+  bool graph_launched = false;
+  // a captured step needs the LDS-resident tier on both stages (no host round trips inside)
+  b->timed = true;
+  const bool capturing = want_graph && st != nullptr && b->fast_ok && (stages & KM_STAGE_WALK);   // the NULL stream cannot be captured
+  if (capturing) {
+    b->timed = false;
+    drop_graph(b);
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  }
   if (stages & KM_STAGE_WALK) {
-    HIPCHK(hipEventRecord(b->ev[0], st));
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
-    HIPCHK(hipEventRecord(b->ev[3], st));
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
       hipLaunchKernelGGL(k_seed, dim3(b->n_items), dim3(SEED_BLOCK), 0, st, wa);
-    HIPCHK(hipEventRecord(b->ev[4], st));
-    if (b->fast_ok)
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
+    if (b->fast_ok) {
+      // unflagged targets are final after k_seed: their pure-chain check runs on the side
+      // stream while k_dfs (latency-bound, few waves) walks the flagged ones
+      HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
+      hipEvent_t e_fork = capturing ? b->ev_cap_seed : b->ev_seed_done;
+      hipEvent_t e_join = capturing ? b->ev_cap_pure : b->ev_pure_done;
+      HIPCHK(hipEventRecord(e_fork, st));
+      HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
+      pure_geometry(b);
+      ga.use_need_full = 1;
+      hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(GRAPH_THREADS), b->pure_lds, b->side, ga);
+      HIPCHK(hipEventRecord(e_join, b->side));
       hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(b->ev[1], st));
+      HIPCHK(hipGetLastError());
+      if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
+      HIPCHK(hipStreamWaitEvent(st, e_join, 0));
+      hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+      HIPCHK(hipGetLastError());
+      graph_launched = true;
+    } else {
+      HIPCHK(hipGetLastError());
+      if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
+    }
     b->ran_walk = true;
     b->ran_graph = false;
     b->big_walk_done = false;
   } else if (!b->ran_walk) {
     return fail(KM_E_STATE, "graph stage requested before the walk stage");
   } else {
-    HIPCHK(hipEventRecord(b->ev[0], st));
-    HIPCHK(hipEventRecord(b->ev[3], st));
-    HIPCHK(hipEventRecord(b->ev[4], st));
-    HIPCHK(hipEventRecord(b->ev[1], st));
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[0], st));
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[3], st));
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
   }
-  // the graph kernel also hosts the duplicate-k-mer check, so it always runs
+  // the graph kernels also host the duplicate-k-mer check, so they always run
   // (graph_mode 1 = stop after that check)
-  {
+  if (!graph_launched) {
     int rc = launch_graph_fast(b, st);
     if (rc != KM_OK) return rc;
   }
   b->ran_graph = true;                      // graph_mode says how far it went
-  HIPCHK(hipEventRecord(b->ev[2], st));
+  if (!capturing) HIPCHK(hipEventRecord(b->ev[2], st));
+  if (capturing) {
+    HIPCHK(hipStreamEndCapture(st, &b->graph));
+    HIPCHK(hipGraphInstantiate(&b->gexec, b->graph, nullptr, nullptr, 0));
+    b->graph_stages = stages;
+    b->graph_stream = st;
+    HIPCHK(hipGraphLaunch(b->gexec, st));
+  }
   b->synced = false;
   return KM_OK;
 }
@@ -884,10 +990,15 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = b->last_stream;
   HIPCHK(hipStreamSynchronize(st));
-  (void)hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]);
-  (void)hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]);
-  (void)hipEventElapsedTime(&b->ms[2], b->ev[0], b->ev[2]);
-  (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
+  if (b->timed) {
+    (void)hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]);
+    (void)hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]);
+    (void)hipEventElapsedTime(&b->ms[2], b->ev[0], b->ev[2]);
+    (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
+    (void)hipGetLastError();
+  } else {
+    b->ms[0] = b->ms[1] = b->ms[2] = b->ms[3] = 0.0f;
+  }
   HIPCHK(hipMemcpy(&b->h_nflagged, b->d_nflagged.p, 4, hipMemcpyDeviceToHost));
   int rc = pull_status(b, st);
   if (rc != KM_OK) return rc;

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkmgpu.so")
 
 KM_OK = 0
-KM_STAGE_WALK, KM_STAGE_GRAPH = 1, 2
+KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH = 1, 2, 4
 T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 
 # every symbol include/kmgpu.h declares (tests check the library exports them all)
@@ -24,7 +24,7 @@ SYMBOLS = [
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
     "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_strerror", "km_last_error",
-    "km_device_count", "km_version",
+    "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
 
 
@@ -100,6 +100,8 @@ def load():
         "km_batch_fetch": [vp, C.POINTER(BatchOut)],
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
         "km_device_count": [C.POINTER(i32)],
+        "km_stream_create": [i32, C.POINTER(vp)],
+        "km_stream_destroy": [vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -110,6 +112,17 @@ def load():
     lib.km_strerror.argtypes = [i32]
     _lib = lib
     return lib
+
+
+def stream_create(device=0):
+    """A non-blocking HIP stream handle (int) from the library."""
+    st = C.c_void_p()
+    check(load().km_stream_create(int(device), C.byref(st)))
+    return st.value
+
+
+def stream_destroy(stream):
+    check(load().km_stream_destroy(C.c_void_p(stream)))
 
 
 def check(rc):

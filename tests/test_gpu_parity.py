@@ -274,9 +274,16 @@ def test_properties_mid_size():
     r1 = b.fetch()
     b.run()
     r2 = b.fetch()
+    # the same step captured into a hipGraph and replayed (twice) gives the same answer
+    both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    st = kmlib.stream_create(0)
+    b.run(both | kmlib.KM_RUN_HIPGRAPH, st)
+    b.run(both | kmlib.KM_RUN_HIPGRAPH, st)
+    r3 = b.fetch()
     for key in ("status", "n_ref", "probes", "node_off", "node_kmer", "node_count", "path_off",
                 "run_off", "run_start", "run_len", "path_len", "path_min_cov"):
         assert (r1[key] == r2[key]).all(), key
+        assert (r1[key] == r3[key]).all(), key
     assert (r1["status"] == 0).all() and (r1["n_ref"] == 470).all()
     # counts stored by the walk == Jellyfish.query of the same k-mers
     assert (db.query(r1["node_kmer"]) == r1["node_count"]).all()
