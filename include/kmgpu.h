@@ -56,9 +56,9 @@ typedef struct {
   int32_t  k;            /* k-mer length (key_len / 2)                        */
   int32_t  canonical;    /* header["canonical"]  (km/utils/Jellyfish.py:45)   */
   uint64_t n_records;    /* records held (count > 0)                          */
-  uint64_t n_slots;      /* device table capacity in 32-byte slots (0 = not uploaded) */
+  uint64_t n_slots;      /* device table capacity in 16-byte slots (0 = not uploaded) */
   uint64_t n_groups;     /* occupied slots                                    */
-  uint64_t table_bytes;  /* n_slots * 32                                      */
+  uint64_t table_bytes;  /* n_slots * 16 + side table of counts >= 65535      */
   int32_t  device;       /* HIP device ordinal of the table, -1 if none       */
   int32_t  reserved;
 } kmjf_info_t;
@@ -82,7 +82,7 @@ typedef struct {
   uint64_t n_nodes;        /* over all targets, caps excluded                  */
   uint64_t n_runs;         /* path run-length records over all paths           */
   uint64_t logical_probes; /* reference-semantics Jellyfish.query calls        */
-  uint64_t table_fetches;  /* 32-byte table slots actually read by the walk    */
+  uint64_t table_fetches;  /* 16-byte table slots actually read by the walk    */
   uint32_t n_big_tier;     /* targets that needed the large-workspace pass     */
   uint32_t n_flagged;      /* targets with at least one non-trivial seed       */
   uint64_t seed_probes;    /* logical probes answered by the k_seed kernel     */

@@ -5,9 +5,9 @@
 // (km/utils/Jellyfish.py:47-53) for the k-mers S+A, S+C, S+G, S+T that share the
 // (k-1)-mer S.  A plain k-mer -> count hash scatters those four over four HBM
 // lines.  Here the open-addressing table is keyed by the *shared (k-1)-mer*
-// instead, so one aligned 32-byte slot answers a whole get_child:
+// instead, so one aligned 16-byte slot (a single dwordx4 load) answers a whole get_child:
 //
-//     slot = { u64 tag ; u32 count[4] ; u64 pad }          (32 B, 32-B aligned)
+//     slot = { u64 tag ; u16 count[4] }                    (16 B, 16-B aligned)
 //     tag  = (G << 1) | side,   G = the canonical (k-1)-mer (min(S, revcomp S))
 //     side 0: count[c] = count of the k-mer  G+c           (right extension)
 //     side 1: count[c] = count of the k-mer  c+G           (left extension)
@@ -18,6 +18,9 @@
 // A lookup of the forward children of X uses P = X[1:] with the same rule, a
 // single query(X) uses P = X[:-1], c = X[-1].  Non-canonical databases store and
 // look up P as is (side 0 only).  Empty slots have tag == ~0 (a valid tag is < 2^63).
+// Counts are stored as u16; a count >= 65535 is stored as 0xFFFF and its exact value
+// lives in a small side table keyed by the canonical k-mer (OvfSlot), consulted only then.
+// HBM serves the table in 128-byte lines (8 slots), so linear probing stays in the line.
 // Linear probing; slot index = mulhi64(mix64(tag), n_slots) (any capacity).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,16 +30,25 @@ namespace kmd {
 
 constexpr uint64_t EMPTY = ~0ull;
 
-struct __attribute__((aligned(32))) Slot {
+struct __attribute__((aligned(16))) Slot {
   uint64_t tag;
-  uint32_t c[4];
-  uint64_t pad;
+  uint16_t c[4];
 };
-static_assert(sizeof(Slot) == 32, "slot must be one 32-byte sector");
+static_assert(sizeof(Slot) == 16, "slot must be one dwordx4");
+constexpr uint32_t COUNT_ESCAPE = 0xFFFFu;
+
+// exact counts >= COUNT_ESCAPE; empty iff count == 0
+struct __attribute__((aligned(16))) OvfSlot {
+  uint64_t kmer;     // canonical k-mer (as stored in the database)
+  uint32_t count;
+  uint32_t pad;
+};
 
 struct TableView {
   const Slot* slots;
   uint64_t n_slots;
+  const OvfSlot* ovf;
+  uint64_t n_ovf;
   uint64_t kmask;   // 2k low bits set
   uint64_t pmask;   // 2(k-1) low bits set
   int k;
@@ -96,28 +108,52 @@ __device__ inline uint32_t pick4(uint4 v, uint32_t i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// Counts of the four members of the group `tag` in slot order (zeros if absent).
-// One 32-byte sector per probe step; *fetches counts the sectors read.
+// Counts of the four members of the group `tag` in slot order (zeros if absent), as
+// stored (u16, possibly COUNT_ESCAPE).  One 16-byte load per probe step; *fetches counts
+// the slots read.
 __device__ inline uint4 table_lookup4(const TableView& t, uint64_t tag, uint32_t* fetches) {
   uint64_t idx = slot_index(tag, t.n_slots);
   for (uint64_t step = 0; step < t.n_slots; ++step) {
-    const uint4* p = reinterpret_cast<const uint4*>(t.slots + idx);
-    uint4 a = p[0];
-    uint2 b = *reinterpret_cast<const uint2*>(p + 1);
+    const uint4 a = *reinterpret_cast<const uint4*>(t.slots + idx);
     ++*fetches;
-    uint64_t tg = ((uint64_t)a.y << 32) | a.x;
-    if (tg == tag) return make_uint4(a.z, a.w, b.x, b.y);
+    const uint64_t tg = ((uint64_t)a.y << 32) | a.x;
+    if (tg == tag) return make_uint4(a.z & 0xFFFFu, a.z >> 16, a.w & 0xFFFFu, a.w >> 16);
     if (tg == EMPTY) break;
     if (++idx == t.n_slots) idx = 0;
   }
   return make_uint4(0, 0, 0, 0);
 }
 
+// Exact count of a k-mer whose stored count is COUNT_ESCAPE.
+__device__ inline uint32_t overflow_count(const TableView& t, uint64_t kmer) {
+  if (t.canonical) {
+    const uint64_t r = revcomp(kmer, t.k);
+    if (r < kmer) kmer = r;
+  }
+  if (t.n_ovf == 0) return COUNT_ESCAPE;
+  uint64_t idx = slot_index(kmer, t.n_ovf);
+  for (uint64_t step = 0; step < t.n_ovf; ++step) {
+    const OvfSlot o = t.ovf[idx];
+    if (o.count == 0) break;
+    if (o.kmer == kmer) return o.count;
+    if (++idx == t.n_ovf) idx = 0;
+  }
+  return COUNT_ESCAPE;
+}
+
 // Counts of X[1:]+A, +C, +G, +T (child-base order).
 __device__ inline uint4 forward_children(const TableView& t, uint64_t X, uint32_t* fetches) {
   Group g = group_of_prefix(X & t.pmask, t.k, t.canonical);
   uint4 c = table_lookup4(t, g.tag, fetches);
-  return g.flip ? make_uint4(c.w, c.z, c.y, c.x) : c;
+  if (g.flip) c = make_uint4(c.w, c.z, c.y, c.x);
+  if (c.x == COUNT_ESCAPE || c.y == COUNT_ESCAPE || c.z == COUNT_ESCAPE || c.w == COUNT_ESCAPE) {
+    const uint64_t base = (X << 2) & t.kmask;
+    if (c.x == COUNT_ESCAPE) c.x = overflow_count(t, base | 0);
+    if (c.y == COUNT_ESCAPE) c.y = overflow_count(t, base | 1);
+    if (c.z == COUNT_ESCAPE) c.z = overflow_count(t, base | 2);
+    if (c.w == COUNT_ESCAPE) c.w = overflow_count(t, base | 3);
+  }
+  return c;
 }
 
 // Jellyfish.query(X): km/utils/Jellyfish.py:47-53.
@@ -125,7 +161,9 @@ __device__ inline uint32_t query_one(const TableView& t, uint64_t X, uint32_t* f
   Group g = group_of_prefix(X >> 2, t.k, t.canonical);
   uint4 c = table_lookup4(t, g.tag, fetches);
   uint32_t s = (uint32_t)(X & 3);
-  return pick4(c, g.flip ? 3 - s : s);
+  uint32_t v = pick4(c, g.flip ? 3 - s : s);
+  if (v == COUNT_ESCAPE) v = overflow_count(t, X);
+  return v;
 }
 
 // Children kept by Jellyfish.get_child: count >= max(sum * cutoff, n_cutoff)

@@ -87,6 +87,8 @@ struct kmjf {
   int device = -1;
   Slot* d_slots = nullptr;
   uint64_t n_slots = 0;
+  OvfSlot* d_ovf = nullptr;
+  uint64_t n_ovf = 0;
   uint64_t n_groups = 0;
 };
 
@@ -96,6 +98,8 @@ static TableView view_of(const kmjf* h) {
   TableView t;
   t.slots = h->d_slots;
   t.n_slots = h->n_slots;
+  t.ovf = h->d_ovf;
+  t.n_ovf = h->n_ovf;
   t.kmask = mask_bits(h->k);
   t.pmask = mask_bits(h->k - 1);
   t.k = h->k;
@@ -152,6 +156,9 @@ static void free_table(kmjf* h) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_slots);
     h->d_slots = nullptr;
+    if (h->d_ovf) (void)hipFree(h->d_ovf);
+    h->d_ovf = nullptr;
+    h->n_ovf = 0;
   }
   h->n_slots = h->n_groups = 0;
   h->device = -1;
@@ -171,7 +178,7 @@ extern "C" int kmjf_info(const kmjf_t* h, kmjf_info_t* info) {
   info->n_records = h->n_records;
   info->n_slots = h->n_slots;
   info->n_groups = h->n_groups;
-  info->table_bytes = h->n_slots * sizeof(Slot);
+  info->table_bytes = h->n_slots * sizeof(Slot) + h->n_ovf * sizeof(OvfSlot);
   info->device = h->device;
   info->reserved = 0;
   return KM_OK;
@@ -208,22 +215,39 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   n_slots = (n_slots + 63) & ~63ull;
   Slot* slots = nullptr;
   HIPCHK(hipMalloc((void**)&slots, n_slots * sizeof(Slot)));
-  unsigned long long* d_meta = nullptr;   // [0] groups, [1] error flag (low 32 bits)
-  hipError_t e = hipMalloc((void**)&d_meta, 16);
+  unsigned long long* d_meta = nullptr;   // [0] groups, [1] error flag (low 32 bits), [2] big counts
+  hipError_t e = hipMalloc((void**)&d_meta, 32);
   if (e != hipSuccess) { (void)hipFree(slots); return fail(KM_E_NOMEM, "hipMalloc failed"); }
-  (void)hipMemsetAsync(d_meta, 0, 16, st);
-  hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots * 2, 256)), dim3(256), 0, st, slots, n_slots);
+  (void)hipMemsetAsync(d_meta, 0, 32, st);
+  // side table for the (rare) counts that do not fit 16 bits
+  unsigned long long n_big = 0;
+  if (n) {
+    hipLaunchKernelGGL(k_count_big, dim3(grid_for(n, 256)), dim3(256), 0, st, d_counts, n, d_meta + 2);
+    e = hipMemcpyAsync(&n_big, d_meta + 2, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(slots); (void)hipFree(d_meta); return fail(KM_E_HIP, "count pass failed: %s", hipGetErrorString(e)); }
+  }
+  OvfSlot* ovf = nullptr;
+  uint64_t n_ovf = n_big ? (n_big * 2 + 64) : 0;
+  if (n_ovf) {
+    e = hipMalloc((void**)&ovf, n_ovf * sizeof(OvfSlot));
+    if (e != hipSuccess) { (void)hipFree(slots); (void)hipFree(d_meta); return fail(KM_E_NOMEM, "hipMalloc failed"); }
+    (void)hipMemsetAsync(ovf, 0, n_ovf * sizeof(OvfSlot), st);
+  }
+  hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
   if (n)
     hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, slots, n_slots,
-                       d_keys, d_counts, n, h->k, h->canonical, d_meta,
+                       d_keys, d_counts, n, h->k, h->canonical, ovf, n_ovf, d_meta,
                        reinterpret_cast<unsigned int*>(d_meta + 1));
   unsigned long long meta[2] = {0, 0};
   e = hipMemcpyAsync(meta, d_meta, 16, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d_meta);
-  if (e != hipSuccess) { (void)hipFree(slots); return fail(KM_E_HIP, "table build failed: %s", hipGetErrorString(e)); }
-  if (meta[1] & 0xFFFFFFFFull) { (void)hipFree(slots); return fail(KM_E_HIP, "table build overflowed"); }
+  if (e != hipSuccess) { (void)hipFree(slots); if (ovf) (void)hipFree(ovf); return fail(KM_E_HIP, "table build failed: %s", hipGetErrorString(e)); }
+  if (meta[1] & 0xFFFFFFFFull) { (void)hipFree(slots); if (ovf) (void)hipFree(ovf); return fail(KM_E_HIP, "table build overflowed"); }
   h->d_slots = slots;
+  h->d_ovf = ovf;
+  h->n_ovf = n_ovf;
   h->n_slots = n_slots;
   h->n_groups = meta[0];
   h->device = device;

@@ -7,18 +7,27 @@ namespace kmd {
 // Fill the table with empty slots.  16 B per lane, fully coalesced.
 __global__ void k_table_init(Slot* slots, uint64_t n_slots) {
   uint4* p = reinterpret_cast<uint4*>(slots);
-  const uint64_t n16 = n_slots * 2;
-  const uint4 first = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-  const uint4 second = make_uint4(0u, 0u, 0u, 0u);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+  const uint4 empty = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots;
        i += (uint64_t)gridDim.x * blockDim.x)
-    p[i] = (i & 1) ? second : first;
+    p[i] = empty;
+}
+
+// Number of records whose count does not fit the 16-bit slot field.
+__global__ void k_count_big(const uint32_t* counts, uint64_t n, unsigned long long* out) {
+  unsigned long long local = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    local += counts[i] >= COUNT_ESCAPE ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
 // One record per thread: enter the k-mer under the group of each orientation.
 // err[0] != 0 on return means the table was too small (never with our sizing).
 __global__ void k_table_insert(Slot* slots, uint64_t n_slots, const uint64_t* keys,
                                const uint32_t* counts, uint64_t n, int k, int canonical,
+                               OvfSlot* ovf, uint64_t n_ovf,
                                unsigned long long* n_groups, unsigned int* err) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
@@ -32,6 +41,16 @@ __global__ void k_table_insert(Slot* slots, uint64_t n_slots, const uint64_t* ke
       if (R < K) continue;            // not canonical: unreachable by query(), as in the reference
       n_or = (R == K) ? 1 : 2;
     }
+    if (v >= COUNT_ESCAPE) {
+      // exact value to the side table (keyed by the k-mer as stored)
+      bool placed = false;
+      uint64_t oi = n_ovf ? slot_index(K, n_ovf) : 0;
+      for (uint64_t step = 0; step < n_ovf; ++step) {
+        if (atomicCAS(&ovf[oi].count, 0u, v) == 0u) { ovf[oi].kmer = K; placed = true; break; }
+        if (++oi == n_ovf) oi = 0;
+      }
+      if (!placed) atomicExch(err, 1u);
+    }
     for (int o = 0; o < n_or; ++o) {
       const uint64_t O = o ? R : K;
       Group g = group_of_prefix(O >> 2, k, canonical);
@@ -44,7 +63,7 @@ __global__ void k_table_insert(Slot* slots, uint64_t n_slots, const uint64_t* ke
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
         if (old == EMPTY) atomicAdd(n_groups, 1ull);
         if (old == EMPTY || old == g.tag) {
-          slots[idx].c[s] = v;
+          slots[idx].c[s] = (uint16_t)(v >= COUNT_ESCAPE ? COUNT_ESCAPE : v);
           done = true;
           break;
         }

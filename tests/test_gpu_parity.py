@@ -309,3 +309,20 @@ def test_properties_mid_size():
             assert ((kms[idx[:-1]] & np.uint64((1 << 60) - 1)) == (kms[idx[1:]] >> np.uint64(2))).all()
         n_var += (pe - pa) > 1
     assert 400 < n_var < 800                                      # ~30 % of targets carry a variant
+
+
+def test_counts_beyond_16_bits_match_oracle():
+    """Stored counts are u16 in the HBM slots; anything >= 65535 goes through the exact
+    side table.  Coverage 40k-400k puts most k-mers (and the 65535 boundary) there."""
+    case = synth.make_case(n_targets=40, length=250, n_keys=30_000, seed=123, variant_frac=0.8,
+                           cov=(40_000, 400_000), vaf=(0.1, 0.9))
+    assert int(case["counts"].max()) > 200_000 and int((case["counts"] < 65535).sum()) > 100
+    # pin the boundary values themselves
+    case["counts"][:6] = np.array([65534, 65535, 65536, 0xFFFFFFFF, 131071, 65535], dtype=np.uint32)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    assert (db.query(case["keys"]) == case["counts"]).all()
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                    records={"k": 31, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+    targets = [(n, km.decode(r)) for n, r in zip(case["names"], case["targets"])]
+    _compare_with_oracle(jf, cpu, targets)
