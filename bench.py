@@ -53,7 +53,20 @@ def cpu_baseline(case, n_sample, k):
         probes += res["probes"]
         rows += len(res["paths"])
     dt = time.perf_counter() - t0
+    # the same work through the plain-C oracle (oracle/km_oracle.c), for scale
+    c_rate = None
+    try:
+        from oracle import c_oracle
+        co = c_oracle.COracle(rec["keys"], rec["counts"], k)
+        n_c = min(len(case["targets"]), 4 * n_sample)
+        t1 = time.perf_counter()
+        for i in range(n_c):
+            co.analyse(case["targets"][i])
+        c_rate = n_c / (time.perf_counter() - t1)
+    except Exception as e:          # the C oracle is optional test infrastructure
+        log("C oracle not timed:", e)
     return {"value": n_sample / dt, "unit": "targets/s", "cores": 1, "kind": "port",
+            "c_oracle_targets_per_s": c_rate,
             "sample": "first %d of the 10000 targets (walk + path search, oracle/km_oracle.py, "
                       "dict-backed table of the %d non-pad keys)" % (n_sample, nr),
             "probes_per_s": probes / dt, "seconds": dt}

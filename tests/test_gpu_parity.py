@@ -326,3 +326,30 @@ def test_counts_beyond_16_bits_match_oracle():
                     records={"k": 31, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
     targets = [(n, km.decode(r)) for n, r in zip(case["names"], case["targets"])]
     _compare_with_oracle(jf, cpu, targets)
+
+
+def test_full_batch_against_c_oracle():
+    """Every target of a config-4 shaped batch (3000 x 500 nt, 2 M keys) against the
+    plain-C oracle: node lists, counts, logical probes, paths, min coverages."""
+    from oracle import c_oracle
+    case = synth.make_case(n_targets=3000, length=500, n_keys=2_000_000, seed=synth.HEADLINE_SEED,
+                           exact_pad=False)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    b = kmlib.Batch(db, max_targets=3000, max_total_bases=3000 * 500)
+    b.set_targets([km.decode(r) for r in case["targets"]])
+    b.run()
+    r = b.fetch()
+    co = c_oracle.COracle(case["keys"][:case["n_real"]], case["counts"][:case["n_real"]], 31)
+    noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
+    n_multi = 0
+    for t in range(3000):
+        want = co.analyse(case["targets"][t])
+        assert want["status"] == 0 and int(r["status"][t]) == 0
+        assert (r["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all(), t
+        assert (r["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all(), t
+        assert int(r["probes"][t]) == want["probes"], t
+        got = [kmlib.expand_path(r, p).tolist() for p in range(poff[t], poff[t + 1])]
+        assert got == want["paths"], t
+        assert r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"], t
+        n_multi += len(got) > 1
+    assert n_multi > 600
