@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify a sample against the oracle")
+    ap.add_argument("--e2e", type=int, default=1000,
+                    help="targets for the end-to-end (strings in -> TSV rows out) measurement")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay each step as one captured hipGraph (measured: no gain, GPU-bound)")
     ap.add_argument("--inflight", type=int, default=4,
@@ -220,6 +222,23 @@ def main():
     res = batch.fetch()
     fetch_s = time.perf_counter() - t_f
 
+    # ---- end to end through the drop-in host path: strings -> GPU -> TSV rows -----------
+    e2e = None
+    if rank == 0 and args.e2e > 0:
+        from km_amd import kmer as km, report
+        from km_amd.finder import BatchFinder
+        from km_amd.jellyfish import Jellyfish
+        n_e = min(args.e2e, T)
+        tg = [(case["names"][i], km.decode(case["targets"][i])) for i in range(n_e)]
+        jf = Jellyfish("synthetic.jf", cutoff=0.05, n_cutoff=5, device=local_rank, db=db)
+        finder = BatchFinder(jf)
+        t_e = time.perf_counter()
+        n_rows = 0
+        for res_t in finder.analyse(tg):
+            n_rows += len(report.target_rows(res_t, jf.filename))
+        e2e = {"targets": n_e, "rows": n_rows, "seconds": time.perf_counter() - t_e}
+        e2e["targets_per_s"] = n_e / e2e["seconds"]
+
     if args.check and rank == 0:
         from km_amd import kmer as km
         from oracle import km_oracle as ko
@@ -277,6 +296,7 @@ def main():
             "hipgraph_replay": bool(args.hipgraph),
             "ms_per_step_unpipelined": serial_ms,
             "result_fetch_ms": fetch_s * 1e3,
+            "end_to_end_host_path": e2e,
             "setup_s": {"generate": t_gen, "h2d_broadcast": t_bcast, "table_build": t_build},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

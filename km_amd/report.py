@@ -208,6 +208,15 @@ def target_rows(res, db_name):
     ref_seq = res.seq[: n_ref + k - 1]
     rows = []
     paths = [np.asarray(p, dtype=np.int64) for p in res.paths]
+    if len(paths) == 1 and paths[0].size == n_ref and (paths[0] == ref).all():
+        # Only the reference path: PathQuant's answer is known in closed form.  Both
+        # coefficients are positive as soon as one k-mer of the path has coverage, and
+        # adjust_for_reference then overwrites them with min(counts incl. the -1 caps) = -1;
+        # with zero coverage everywhere rVAF aliases coef and both print as nan
+        # (km/utils/PathQuant.py:144-154).  No cluster is reported for the reference alone.
+        expr = float("nan") if int(res.counts[:n_ref].max()) == 0 else -1.0
+        return [format_row(db_name, res.name, "Reference\t", float("nan"), expr, res.min_cov[0], 0,
+                           ref_seq, expr, ref_seq, "vs_ref")]
     for p, mc in zip(paths, res.min_cov):
         coef, rvaf = fit_paths([p, ref], counts_f32, n_total)
         if p.size == n_ref and (p == ref).all():
