@@ -61,7 +61,7 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
               variant_frac=0.30, variants_per_target=(1, 1), vaf=(0.1, 0.6),
               kinds=("snv", "ins", "del", "dup"), noise_frac=0.01, noise_counts=(2, 5),
               cov=(50, 2000), hom_frac=0.0, branch_noise_frac=0.0, name=None,
-              exact_pad=True, **_):
+              exact_pad=True, canonical=True, **_):
     """Build targets + (keys, counts).  Returns dict(targets=uint8[n,L] codes,
     names, keys uint64 (canonical, distinct), counts uint32, k)."""
     rng = np.random.default_rng(seed)
@@ -116,7 +116,8 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
 
     keys = np.concatenate([ref_km.ravel()] + add_keys) if add_keys else ref_km.ravel()
     cnts = np.concatenate([ref_cnt.ravel()] + add_cnts) if add_cnts else ref_cnt.ravel()
-    keys = km.canonical(keys, k)
+    if canonical:
+        keys = km.canonical(keys, k)
     keep = cnts > 0
     keys, cnts = keys[keep], cnts[keep]
     uk, first = np.unique(keys, return_index=True)          # first occurrence wins
@@ -132,7 +133,9 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
         while left > 0:
             m = min(left, 1 << 24)
             hi = (1 << (2 * k)) if 2 * k < 64 else int(np.iinfo(np.uint64).max)
-            pad = km.canonical(rng.integers(0, hi, size=m, dtype=np.uint64), k)
+            pad = rng.integers(0, hi, size=m, dtype=np.uint64)
+            if canonical:
+                pad = km.canonical(pad, k)
             pos = np.searchsorted(keys, pad)
             pos[pos >= keys.size] = keys.size - 1
             ok = keys[pos] != pad
@@ -142,9 +145,10 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
         keys = np.concatenate(chunks_k)
         cnts = np.concatenate(chunks_c)
     elif n_pad:
-        pad = km.canonical(rng.integers(0, 1 << (2 * k), size=n_pad, dtype=np.uint64)
-                           if 2 * k < 64 else rng.integers(0, np.iinfo(np.uint64).max, size=n_pad,
-                                                           dtype=np.uint64), k)
+        pad = (rng.integers(0, 1 << (2 * k), size=n_pad, dtype=np.uint64)
+               if 2 * k < 64 else rng.integers(0, np.iinfo(np.uint64).max, size=n_pad, dtype=np.uint64))
+        if canonical:
+            pad = km.canonical(pad, k)
         padc = rng.integers(2, 51, size=n_pad)
         keys = np.concatenate([keys, pad])
         cnts = np.concatenate([cnts, padc])

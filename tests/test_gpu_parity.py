@@ -353,3 +353,27 @@ def test_full_batch_against_c_oracle():
         assert r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"], t
         n_multi += len(got) > 1
     assert n_multi > 600
+
+
+@pytest.mark.parametrize("k,canonical", [(32, True), (15, True), (31, False), (24, False)])
+def test_other_k_and_non_canonical_databases(k, canonical):
+    """k = 32 fills the whole uint64 key; non-canonical databases are looked up as stored
+    (km/utils/Jellyfish.py:51-52 canonicalises only when the header says so)."""
+    case = synth.make_case(n_targets=40, length=220, k=k, n_keys=20_000, seed=1000 + k,
+                           variant_frac=0.8, branch_noise_frac=0.02, canonical=canonical)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], k, canonical).upload(0)
+    assert (db.query(case["keys"]) == case["counts"]).all()
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    assert jf.k == k and jf.canonical == canonical
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                    records={"k": k, "canonical": canonical, "keys": case["keys"], "counts": case["counts"]})
+    targets = [(n, km.decode(r)) for n, r in zip(case["names"], case["targets"])]
+    got = _compare_with_oracle(jf, cpu, targets)
+    # TSV rows too (naming uses k)
+    for (name, seq), g in zip(targets[:10], got[:10]):
+        want = ko.analyse_target(seq, name, cpu)
+        assert report.target_rows(g, "mem.jf") == ko.target_rows(want, "mem.jf")
+    # backward children on a non-trivial k
+    seqs = [km.unpack(x, k) for x in case["keys"][:30]]
+    for s_ in seqs:
+        assert jf.get_child(s_, forward=False) == cpu.get_child(s_, forward=False)
