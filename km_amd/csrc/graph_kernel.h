@@ -127,7 +127,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph_pure(GraphArgs a) {
   if (a.tflag[t]) return;                      // k_graph handles it once k_dfs is done
   const uint32_t n_ref = a.n_ref[t];
   const uint32_t hcap = a.hcap_pure;
-  if ((uint64_t)3 * (n_ref + 2) > (uint64_t)2 * hcap || a.dbg != 0) {
+  if ((uint64_t)3 * (n_ref + 2) > (uint64_t)2 * hcap || (a.dbg != 0 && !(a.dbg & 0x80u))) {
     if (tid == 0) a.need_full[t] = 1;
     return;
   }
@@ -187,7 +187,10 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph_pure(GraphArgs a) {
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
+__global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
+  GraphArgs a = a0;
+  const bool keep_pure = (a.dbg & 0x80u) != 0;   // ablation: pure pass stays active
+  a.dbg &= 0x7Fu;
   using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
   constexpr idx_t NONE = (idx_t)~(idx_t)0;
   constexpr uint32_t NIL = 0xFFFFFFFFu;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a) {
   // either).  Then both Dijkstra trees are the chain, every reference edge but the first
   // is stripped, and edges (source,0) and (0,1) both generate the one path 0..n_ref-1.
   {
-    uint32_t not_pure = shared_prefix | (m != n_ref ? 1u : 0u) | (a.dbg != 0 ? 1u : 0u);
+    uint32_t not_pure = shared_prefix | (m != n_ref ? 1u : 0u) | ((a.dbg != 0 && !keep_pure) ? 1u : 0u);
     if (tid == 0 && !not_pure) {
       const uint64_t S = nk[m - 1] & a.pmask;
       uint32_t s = set_home(S, hcap);

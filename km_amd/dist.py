@@ -105,3 +105,22 @@ def find_mutation_sharded(targets, db_path, analyse, load_records=None):
     lo, hi = shard_range(len(targets), rank, world)
     rows = analyse(d_keys, d_cnts, n, k, canonical, targets[lo:hi])
     return gather_in_order(rows)
+
+
+def find_mutation_samples(db_paths, run_sample):
+    """Sample-sharded runs (BASELINE config 5; the shape of example/run_leucegene.sh:29-35):
+    rank r opens and processes db_paths[r], db_paths[r + world], ... entirely on its own GPU
+    (`run_sample(path) -> list[str]`); there is no collective on this path, only the final
+    gather of the printed rows, in sample order, on rank 0."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = [(i, run_sample(p)) for i, p in enumerate(db_paths) if i % world == rank]
+    if world == 1:
+        return [rows for _, rows in mine]
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(mine, bucket, dst=0)
+    if rank != 0:
+        return None
+    merged = sorted((item for part in bucket for item in part), key=lambda x: x[0])
+    return [rows for _, rows in merged]

@@ -72,7 +72,7 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
     jitter = rng.uniform(0.9, 1.1, size=ref_km.shape)
     ref_cnt = np.maximum(1, np.rint(base_cov[:, None] * jitter)).astype(np.int64)
 
-    add_keys, add_cnts = [], []
+    add_keys, add_cnts, add_tids = [], [], []
     has_var = rng.random(n_targets) < variant_frac
     for t in np.nonzero(has_var)[0]:
         nv = int(rng.integers(variants_per_target[0], variants_per_target[1] + 1))
@@ -89,6 +89,7 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
             c = np.maximum(0, np.rint(base_cov[t] * f * rng.uniform(0.9, 1.1, size=alt.size)))
             add_keys.append(alt)
             add_cnts.append(c.astype(np.int64))
+            add_tids.append(np.full(alt.size, t, dtype=np.int32))
             # ref k-mers spanning the replaced site lose the variant's share
             s0, s1 = max(0, lo - k + 1), min(n_ref, max(hi, lo + 1))
             span = np.arange(s0, s1)
@@ -109,6 +110,7 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
             c = rng.integers(lo_c, hi_c, size=tt.size)
         add_keys.append(sib)
         add_cnts.append(c.astype(np.int64))
+        add_tids.append(tt.astype(np.int32))
 
     siblings(noise_frac, noise_counts[0], noise_counts[1], False)
     if branch_noise_frac:
@@ -116,12 +118,14 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
 
     keys = np.concatenate([ref_km.ravel()] + add_keys) if add_keys else ref_km.ravel()
     cnts = np.concatenate([ref_cnt.ravel()] + add_cnts) if add_cnts else ref_cnt.ravel()
+    ref_tid = np.repeat(np.arange(n_targets, dtype=np.int32), n_ref)
+    tids = np.concatenate([ref_tid] + add_tids) if add_tids else ref_tid
     if canonical:
         keys = km.canonical(keys, k)
     keep = cnts > 0
-    keys, cnts = keys[keep], cnts[keep]
+    keys, cnts, tids = keys[keep], cnts[keep], tids[keep]
     uk, first = np.unique(keys, return_index=True)          # first occurrence wins
-    keys, cnts = uk, cnts[first]
+    keys, cnts, tids = uk, cnts[first], tids[first]
 
     n_real = int(keys.size)
     n_pad = max(0, n_keys - keys.size)
@@ -156,7 +160,9 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
         keys, cnts = uk, cnts[first]
     names = ["%s%05d" % ((name or "syn") + "_t", i) for i in range(n_targets)]
     return {"targets": rows, "names": names, "keys": keys.astype(np.uint64),
-            "counts": np.minimum(cnts, 0xFFFFFFFF).astype(np.uint32), "k": k, "n_real": n_real}
+            "counts": np.minimum(cnts, 0xFFFFFFFF).astype(np.uint32), "k": k, "n_real": n_real,
+            # target each of the first n_real (non-pad) keys was generated for
+            "key_target": tids}
 
 
 def write_jf(path, keys, counts, k, canonical=True):

@@ -45,6 +45,18 @@ lo, hi = kd.shard_range(len(targets), rank, world)
 out = {"rank": rank, "shard": [lo, hi], "n_records": seen["n"]}
 if rank == 0:
     out["rows"] = [r for per_target in rows for r in per_target]
+
+# sample-sharded: each rank opens its own databases, no broadcast
+SAMPLES = ["./data/jf/" + f for f in sorted(os.listdir("./data/jf"))]
+opened = []
+def run_sample(path):
+    opened.append(path)
+    db = ko.KmerDB(path, cutoff=0.05, n_cutoff=5)
+    return [r for name, seq in targets for r in ko.target_rows(ko.analyse_target(seq, name, db), path)]
+per_sample = kd.find_mutation_samples(SAMPLES, run_sample)
+out["opened"] = opened
+if rank == 0:
+    out["per_sample"] = per_sample
 print("RESULT " + json.dumps(out), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -80,3 +92,10 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     gold = json.load(open(os.path.join(HERE, "golden", "fixtures_tsv.json")))
     case = [c for c in gold["cases"] if len(c["targets"]) == 9 and c["db"].endswith("03H116_ITD.jf")][0]
     assert by_rank[0]["rows"] == case["lines"][11:]      # after the 10 '#' lines + header
+    # sample-sharded run: 5 databases over 2 ranks, rows back in sample order
+    dbs = sorted(os.listdir(os.path.join(HERE, "data", "jf")))
+    assert by_rank[0]["opened"] == ["./data/jf/" + d for d in dbs[0::2]]
+    assert by_rank[1]["opened"] == ["./data/jf/" + d for d in dbs[1::2]]
+    for d, rows in zip(dbs, by_rank[0]["per_sample"]):
+        want = [c for c in gold["cases"] if len(c["targets"]) == 9 and c["db"].endswith(d)][0]
+        assert rows == want["lines"][11:]
