@@ -118,9 +118,10 @@ def fit_paths(paths, counts_f32, n_total):
     """Least squares + projected gradient refinement of per-path expression.
     Returns (coef, rvaf); rvaf aliases coef when every coefficient is zero, as in
     the reference."""
-    contrib = np.zeros((n_total, len(paths)), dtype=np.int32)
+    # occurrences of every node on every path (a tandem-duplication path visits nodes twice)
+    contrib = np.empty((n_total, len(paths)), dtype=np.int32)
     for col, p in enumerate(paths):
-        np.add.at(contrib[:, col], np.asarray(p, dtype=np.intp), 1)
+        contrib[:, col] = np.bincount(p, minlength=n_total)
     coef = np.linalg.lstsq(contrib, counts_f32, rcond=None)[0]
     coef[coef < 0] = 0
     step = np.inf
@@ -218,11 +219,13 @@ def target_rows(res, db_name):
         return [format_row(db_name, res.name, "Reference\t", float("nan"), expr, res.min_cov[0], 0,
                            ref_seq, expr, ref_seq, "vs_ref")]
     for p, mc in zip(paths, res.min_cov):
-        coef, rvaf = fit_paths([p, ref], counts_f32, n_total)
         if p.size == n_ref and (p == ref).all():
-            rvaf[0] = np.nan
-            rvaf[1] = np.nan
-            coef[coef >= 0] = min(counts_f32)
+            # the reference against itself: same closed form as above
+            expr = float("nan") if int(res.counts[:n_ref].max()) == 0 else -1.0
+            rows.append(format_row(db_name, res.name, "Reference\t", float("nan"), expr, mc, 0,
+                                   ref_seq, expr, ref_seq, "vs_ref"))
+            continue
+        coef, rvaf = fit_paths([p, ref], counts_f32, n_total)
         rows.append(format_row(db_name, res.name, name_variant(res, tails, ref, p), rvaf[0], coef[0],
                                mc, 0, res.spell(p, tails), coef[1], ref_seq, "vs_ref"))
     if paths:
