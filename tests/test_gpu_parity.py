@@ -377,3 +377,57 @@ def test_other_k_and_non_canonical_databases(k, canonical):
     seqs = [km.unpack(x, k) for x in case["keys"][:30]]
     for s_ in seqs:
         assert jf.get_child(s_, forward=False) == cpu.get_child(s_, forward=False)
+
+
+def test_randomized_parameter_sweep_against_c_oracle():
+    """Random k / lengths / coverage regimes / thresholds / budgets: statuses, node lists,
+    counts, logical probes, paths and min coverages must equal the plain-C oracle's."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(20261003)
+    n_cases = n_limit = n_multi = 0
+    for trial in range(36):
+        k = int(rng.choice([11, 17, 21, 25, 31, 31, 31, 32]))
+        length = int(rng.integers(k + 3, 700))
+        spec = dict(n_targets=int(rng.integers(4, 24)), length=length, k=k, n_keys=5000,
+                    seed=int(rng.integers(1, 1 << 30)), variant_frac=float(rng.choice([0.3, 1.0])),
+                    variants_per_target=(1, int(rng.integers(1, 4))),
+                    vaf=(0.05, 0.95), hom_frac=float(rng.choice([0.0, 0.3])),
+                    branch_noise_frac=float(rng.choice([0.0, 0.02, 0.08])),
+                    noise_frac=float(rng.choice([0.0, 0.05])),
+                    cov=tuple(sorted(rng.choice([2, 8, 40, 400, 3000, 90000], size=2, replace=False).tolist())))
+        if length < 2 * k + 4:
+            spec["variant_frac"] = 0.0            # no room for a variant with k-1 flanks
+        case = synth.make_case(**spec)
+        n_ref = length - k + 1
+        ratio = float(rng.choice([0.0, 0.01, 0.05, 0.05, 0.05, 0.3, 1.0]))
+        count = int(rng.choice([0, 1, 5, 5, 5, 50]))
+        steps = int(rng.choice([1, 2, 7, 60, 500, 500, 500]))
+        branchs = int(rng.choice([0, 1, 3, 10, 10, 10]))
+        nodes = int(rng.choice([n_ref - 1, n_ref, n_ref + 3, n_ref + 40, 10000, 10000, 10000, 10000]))
+        db = kmlib.Database.from_records(case["keys"], case["counts"], k).upload(0)
+        b = kmlib.Batch(db, ratio=ratio, count=count, max_stack=steps, max_break=branchs,
+                        max_node=max(nodes, 0), max_targets=64, max_total_bases=64 * 800)
+        b.set_targets([km.decode(r) for r in case["targets"]])
+        b.run()
+        r = b.fetch()
+        co = c_oracle.COracle(case["keys"], case["counts"], k)
+        noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
+        for t in range(spec["n_targets"]):
+            want = co.analyse(case["targets"][t], ratio=ratio, count=count, max_stack=steps,
+                              max_break=branchs, max_node=max(nodes, 0))
+            ctx = (trial, t, k, length, ratio, count, steps, branchs, nodes)
+            assert int(r["status"][t]) == want["status"], ctx
+            n_cases += 1
+            if want["status"] == 1:
+                n_limit += 1
+                continue
+            assert (r["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all(), ctx
+            assert (r["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all(), ctx
+            assert int(r["probes"][t]) == want["probes"], ctx
+            got = [kmlib.expand_path(r, p).tolist() for p in range(poff[t], poff[t + 1])]
+            assert got == want["paths"], ctx
+            assert r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"], ctx
+            n_multi += len(got) > 1
+        b.close()
+        db.close()
+    assert n_cases > 300 and n_limit > 5 and n_multi > 25, (n_cases, n_limit, n_multi)
