@@ -149,6 +149,9 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     info = db.info
+    # a resident sample of stored k-mers for the probe-only microbenchmark below
+    n_probe = int(min(n_rec, T * (args.length - K + 1)))
+    d_probe = d_keys[torch.randperm(n_rec, device=dev)[:n_probe]].contiguous() if rank == 0 else None
     del d_keys, d_cnts
     torch.cuda.empty_cache()
 
@@ -198,6 +201,9 @@ def main():
         dt = float(tmax.item())
     for bq in batches:
         bq.sync()
+    # k_seed as it ran inside the timed region (the last launch of every workspace; with
+    # several batches in flight it shares the GPU with the other batches' kernels)
+    seed_pipelined_ms = float(np.mean([bq.timings()[3] for bq in batches])) if not args.hipgraph else None
 
     # ---- latency of one isolated step (no pipelining) --------------------------------------
     torch.cuda.synchronize()
@@ -242,6 +248,36 @@ def main():
             n_rows += len(report.target_rows(res_t, jf.filename))
         e2e = {"targets": n_e, "rows": n_rows, "seconds": time.perf_counter() - t_e}
         e2e["targets_per_s"] = n_e / e2e["seconds"]
+
+    # ---- probe kernels alone (rows A2 / A3): Jellyfish.query and get_child for a resident
+    #      array of stored k-mers in random order; 12 resp. 48 algorithmic bytes per element
+    probe = None
+    if rank == 0 and d_probe is not None:
+        d_out = torch.empty(n_probe, dtype=torch.int32, device=dev)
+        d_mask = torch.empty(n_probe, dtype=torch.uint8, device=dev)
+        d_c4 = torch.empty((n_probe, 4), dtype=torch.int32, device=dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        for _ in range(2):
+            db.query_dev(d_probe.data_ptr(), n_probe, d_out.data_ptr(), stream)
+            db.children_dev(d_probe.data_ptr(), n_probe, 0.05, 5, d_mask.data_ptr(), d_c4.data_ptr(), True, stream)
+        reps = 10
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            db.query_dev(d_probe.data_ptr(), n_probe, d_out.data_ptr(), stream)
+        e1.record()
+        for _ in range(reps):
+            db.children_dev(d_probe.data_ptr(), n_probe, 0.05, 5, d_mask.data_ptr(), d_c4.data_ptr(), True, stream)
+        e2.record()
+        torch.cuda.synchronize()
+        q_ms, c_ms = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
+        probe = {"n_kmers": n_probe,
+                 "query": {"ms": q_ms, "G_probes_per_s": n_probe / q_ms / 1e6,
+                           "achieved_GBs": n_probe * 12 / q_ms / 1e6, "frac": n_probe * 12 / q_ms / 1e6 / HBM_PEAK_GBS},
+                 "get_child": {"ms": c_ms, "G_probes_per_s": 4 * n_probe / c_ms / 1e6,
+                               "achieved_GBs": n_probe * 48 / c_ms / 1e6, "frac": n_probe * 48 / c_ms / 1e6 / HBM_PEAK_GBS}}
+        assert int((d_out == 0).sum().item()) == 0        # every stored k-mer is found
+        del d_out, d_mask, d_c4
 
     # ---- BASELINE config 2: latency of ONE target (FLT3-ITD, 75-nt ITD, walk depth 65) ----
     single = None
@@ -324,6 +360,7 @@ def main():
             "result_fetch_ms": fetch_s * 1e3,
             "end_to_end_host_path": e2e,
             "single_target_latency": single,
+            "probe_kernels": probe,
             "setup_s": {"generate": t_gen, "h2d_broadcast": t_bcast, "table_build": t_build},
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -331,6 +368,7 @@ def main():
                          "algorithmic_bytes_per_launch": seed_probes * BYTES_PER_PROBE,
                          "logical_probes_per_launch": seed_probes,
                          "avg_launch_ms": seed_avg,
+                         "avg_launch_ms_inside_pipelined_region": seed_pipelined_ms,
                          "walk_stage_achieved_GBs": walk_achieved},
         }
         if not args.no_cpu:

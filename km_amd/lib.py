@@ -215,6 +215,18 @@ class Database:
                                                 C.c_void_p(stream or 0)))
         return self
 
+    def query_dev(self, d_kmers_ptr, n, d_counts_ptr, stream=None):
+        """Device arrays in / out, asynchronous on `stream`."""
+        check(self._lib.kmjf_query_batch_dev(self._h, C.c_void_p(d_kmers_ptr), int(n),
+                                             C.c_void_p(d_counts_ptr), C.c_void_p(stream or 0)))
+
+    def children_dev(self, d_kmers_ptr, n, ratio, n_cutoff, d_mask_ptr, d_counts4_ptr, forward=True,
+                     stream=None):
+        check(self._lib.kmjf_children_batch_dev(self._h, C.c_void_p(d_kmers_ptr), int(n), float(ratio),
+                                                int(n_cutoff), int(bool(forward)),
+                                                C.c_void_p(d_mask_ptr), C.c_void_p(d_counts4_ptr),
+                                                C.c_void_p(stream or 0)))
+
     def query(self, kmers):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
         out = np.zeros(kmers.size, dtype=np.uint32)
