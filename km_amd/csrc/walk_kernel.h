@@ -11,7 +11,7 @@
 //
 //  k_seed  (one THREAD per target k-mer, flat over the whole batch, no per-target
 //          LDS state, full occupancy — the HBM-bound part and ~85 % of all logical
-//          probes).  Thread (t, i) fetches ONE 32-byte sibling bucket
+//          probes).  Thread (t, i) fetches ONE 16-byte sibling-bucket slot
 //          (device_common.h) which yields the four child counts of
 //          get_child(ref[i]) AND the count of ref[i+1], thresholds the children
 //          and classifies the seed: "trivial" when it has no child or its only

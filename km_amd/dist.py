@@ -3,7 +3,7 @@ is RCCL on ROCm; "gloo" for CPU rehearsals).
 
 The path shards embarrassingly by target: every (target x sample)
 unit is independent.  The only exchange is ONE broadcast of the database —
-the compact record arrays (12 B per k-mer), not the 32 B-per-slot table: every
+the compact record arrays (12 B per k-mer), not the sparse 16 B-per-slot table: every
 rank then builds its own HBM table with the insert kernel, which is far cheaper
 than moving the sparse table over xGMI.  Results return to rank 0 in input order.
 No collective sits on the data path.
