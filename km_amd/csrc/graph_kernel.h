@@ -94,7 +94,7 @@ struct GraphArgs {
 template <typename idx_t>
 __host__ __device__ inline uint64_t graph_region_a(uint32_t ncap, uint32_t hcap) {
   const uint64_t tab = (uint64_t)hcap * (8 + 4 * sizeof(idx_t));   // prefix keys + 4 indices
-  const uint64_t run = (uint64_t)ncap * (8 + 5 * sizeof(idx_t));   // dist_f/b, before, after, frontier, cand(2)
+  const uint64_t run = (uint64_t)ncap * (8 + 6 * sizeof(idx_t));   // dist_f/b, before, after, frontier x2, cand(2)
   return ((tab > run ? tab : run) + 15) & ~15ull;
 }
 
@@ -102,7 +102,7 @@ template <typename idx_t>
 __host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap) {
   uint64_t b = graph_region_a<idx_t>(ncap, hcap);
   b += (((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull;  // succ, pred
-  b += (uint64_t)((ncap + 31) / 32) * 4 * 2;                  // link, inq bits
+  b += (uint64_t)((ncap + 31) / 32) * 4 * 3;                  // link, inq (forward / backward) bits
   b += (uint64_t)((4 * (uint64_t)ncap + 2 + 31) / 32) * 4;    // removed bits
   b += 32;                                                    // scalars
   return (b + 15) & ~15ull;
@@ -238,8 +238,9 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   float* dist_b = dist_f + ncap;
   idx_t* before = reinterpret_cast<idx_t*>(dist_b + ncap);
   idx_t* after = before + ncap;
-  idx_t* frontier = after + ncap;
-  idx_t* cand = frontier + ncap;                   // pairs (a, b)
+  idx_t* frontier = after + ncap;                  // forward pass
+  idx_t* frontier_b = frontier + ncap;             // backward pass
+  idx_t* cand = frontier_b + ncap;                 // pairs (a, b)
   const uint32_t ccap = ncap;
   // persistent
   unsigned char* pp = wsb + graph_region_a<idx_t>(ncap, hcap);
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   const uint32_t nbw = (ncap + 31) / 32;
   uint32_t* link = reinterpret_cast<uint32_t*>(pp);
   uint32_t* inq = link + nbw;
-  uint32_t* removed = inq + nbw;
+  uint32_t* inq_b = inq + nbw;
+  uint32_t* removed = inq_b + nbw;
   const uint32_t n_removed_words = (uint32_t)((4 * (uint64_t)ncap + 2 + 31) / 32);
   uint32_t* scal = removed + n_removed_words;      // [0] candidate count, [1] pool flag
 
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     uint4* q = reinterpret_cast<uint4*>(wsb);
     for (uint64_t x = tid; x < (uint64_t)hcap / 2; x += NT) q[x] = ones;      // hcap keys, 8 B each
   }
-  for (uint32_t w = tid; w < nbw; w += NT) { link[w] = 0; inq[w] = 0; }
+  for (uint32_t w = tid; w < nbw; w += NT) { link[w] = 0; inq[w] = 0; inq_b[w] = 0; }
   for (uint32_t w = tid; w < n_removed_words; w += NT) removed[w] = 0;
   if (tid < 8) scal[tid] = 0;
   __syncthreads();
@@ -432,14 +434,17 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
 
   if (a.dbg == 3) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
   // ---- 3. exact distances -------------------------------------------------------------
-  if (wave == 0) {
-  for (int dir = 0; dir < 2; ++dir) {
+  // the two passes are independent: wave 0 runs the forward one, wave 1 the backward one
+  if (wave < 2) {
+  {
+    const int dir = (int)wave;
     float* dist = dir ? dist_b : dist_f;
     const idx_t* adj = dir ? pred : succ;
+    idx_t* fr = dir ? frontier_b : frontier;
+    uint32_t* iq = dir ? inq_b : inq;
     uint32_t fcount = 0;
     uint32_t cur = dir ? n_ref - 1 : 0;
     float d = 0.0f + W_REF;                                         // cap edge from the root
-    if (dir == 1) { for (uint32_t w = lane; w < nbw; w += 64) inq[w] = 0; }
     if (lane == 0) { dist[dir ? snk : src] = 0.0f; dist[cur] = d; }
     wsync();
     uint32_t guard = 0;
@@ -504,13 +509,13 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
         if (nd < dist[v]) {
           dist[v] = nd;
           // caps are never expanded; other nodes enter the frontier once
-          if (v < m && !((inq[v >> 5] >> (v & 31)) & 1u)) push = true;
+          if (v < m && !((iq[v >> 5] >> (v & 31)) & 1u)) push = true;
         }
       }
       const unsigned long long pm = __ballot(push);
       if (push) {
-        frontier[fcount + (uint32_t)__popcll(pm & ((1ull << lane) - 1))] = (idx_t)v;
-        atomicOr(&inq[v >> 5], 1u << (v & 31));
+        fr[fcount + (uint32_t)__popcll(pm & ((1ull << lane) - 1))] = (idx_t)v;
+        atomicOr(&iq[v >> 5], 1u << (v & 31));
       }
       fcount += (uint32_t)__popcll(pm);
       wsync();
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
         for (uint32_t base = 0; base < fcount; base += 64) {
           const uint32_t p = base + lane;
           unsigned long long key = ~0ull;
-          if (p < fcount) key = ((unsigned long long)__float_as_uint(dist[frontier[p]]) << 32) | p;
+          if (p < fcount) key = ((unsigned long long)__float_as_uint(dist[fr[p]]) << 32) | p;
           for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(key, o);
             key = other < key ? other : key;
@@ -531,15 +536,15 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
         }
         pos = (uint32_t)(best & 0xFFFFFFFFu);
       }
-      cur = frontier[pos];
+      cur = fr[pos];
       d = dist[cur];
       wsync();
-      if (lane == 0) frontier[pos] = frontier[fcount - 1];
+      if (lane == 0) fr[pos] = fr[fcount - 1];
       --fcount;
       wsync();
     }
   }
-  }   // wave 0
+  }   // waves 0, 1
   __syncthreads();
 
   if (a.dbg == 4) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
