@@ -1,27 +1,37 @@
 // device_common.h — k-mer arithmetic, the HBM table layout and its probe.
 //
-// TABLE LAYOUT ("sibling buckets").  The reference's innermost operation is
-// Jellyfish.get_child (km/utils/Jellyfish.py:55-72): four Jellyfish.query calls
-// (km/utils/Jellyfish.py:47-53) for the k-mers S+A, S+C, S+G, S+T that share the
-// (k-1)-mer S.  A plain k-mer -> count hash scatters those four over four HBM
-// lines.  Here the open-addressing table is keyed by the *shared (k-1)-mer*
-// instead, so one aligned 16-byte slot (a single dwordx4 load) answers a whole get_child:
+// TABLE LAYOUT ("sibling slots in minimizer buckets").  The reference's innermost
+// operation is Jellyfish.get_child (km/utils/Jellyfish.py:55-72): four Jellyfish.query
+// calls (km/utils/Jellyfish.py:47-53) for the k-mers S+A, S+C, S+G, S+T that share the
+// (k-1)-mer S.  A plain k-mer -> count hash scatters those four over four HBM lines, and
+// the next step of a walk (S shifted by one base) over four more.  Here
 //
-//     slot = { u64 tag ; u16 count[4] }                    (16 B, 16-B aligned)
-//     tag  = (G << 1) | side,   G = the canonical (k-1)-mer (min(S, revcomp S))
-//     side 0: count[c] = count of the k-mer  G+c           (right extension)
-//     side 1: count[c] = count of the k-mer  c+G           (left extension)
+//  (1) one aligned 16-byte slot (a single dwordx4 load) answers a whole get_child:
+//        slot = { u64 tag ; u16 count[4] }
+//        tag  = (G << 1) | side,   G = the canonical (k-1)-mer (min(S, revcomp S))
+//        side 0: count[c] = count of the k-mer  G+c           (right extension)
+//        side 1: count[c] = count of the k-mer  c+G           (left extension)
+//      A stored canonical k-mer K is entered twice, once for each orientation
+//      O in {K, revcomp K}: with P = O[:-1], c = O[-1]:  P <= revcomp(P) -> (P, side 0,
+//      slot c), else (revcomp P, side 1, slot 3-c)  [revcomp(P+c) = comp(c)+revcomp(P)].
+//      A lookup of the forward children of X uses P = X[1:] with the same rule, a single
+//      query(X) uses P = X[:-1], c = X[-1].  Non-canonical databases store and look up
+//      P as is (side 0 only).  Empty slots have tag == ~0 (a valid tag is < 2^63).
 //
-// A stored canonical k-mer K is entered twice, once for each orientation
-// O in {K, revcomp K}: with P = O[:-1], c = O[-1]:  P <= revcomp(P) -> (P, side 0,
-// slot c), else (revcomp P, side 1, slot 3-c)  [because revcomp(P+c) = comp(c)+revcomp(P)].
-// A lookup of the forward children of X uses P = X[1:] with the same rule, a
-// single query(X) uses P = X[:-1], c = X[-1].  Non-canonical databases store and
-// look up P as is (side 0 only).  Empty slots have tag == ~0 (a valid tag is < 2^63).
+//  (2) slots are grouped into variable-size buckets by the MINIMIZER of P (the m-mer of
+//      P, m = 15 for k = 31, whose canonical form has the smallest order hash):
+//        dir[b] .. dir[b+1]  = the entries of bucket b (an exclusive prefix sum, u32),
+//        bucket b owns the slots [unit*dir[b], unit*dir[b+1])  (unit = 2: load <= 0.5).
+//      Consecutive (k-1)-mers of a sequence share their minimizer for ~(w+1)/2 steps
+//      (w = k-m windows), i.e. they live in the same bucket.  Inside the bucket the home
+//      position is ORDER PRESERVING in (strand of the minimizer, its offset in P): the
+//      next (k-1)-mer of a walk sits in the next slot (linear probing resolves clashes),
+//      so ~8 consecutive lookups of a target share one or two 128-byte HBM lines and one
+//      directory word instead of touching 8 random lines.  Because every bucket is sized
+//      from its own entry count, a heavy minimizer cannot overfill its neighbourhood.
+//
 // Counts are stored as u16; a count >= 65535 is stored as 0xFFFF and its exact value
 // lives in a small side table keyed by the canonical k-mer (OvfSlot), consulted only then.
-// HBM serves the table in 128-byte lines (8 slots), so linear probing stays in the line.
-// Linear probing; slot index = mulhi64(mix64(tag), n_slots) (any capacity).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,14 +56,29 @@ struct __attribute__((aligned(16))) OvfSlot {
 
 struct TableView {
   const Slot* slots;
-  uint64_t n_slots;
+  const uint32_t* dir;   // [n_buckets + 1] exclusive prefix sum of entries per bucket
+  uint64_t n_slots;      // unit * dir[n_buckets]
   const OvfSlot* ovf;
   uint64_t n_ovf;
-  uint64_t kmask;   // 2k low bits set
-  uint64_t pmask;   // 2(k-1) low bits set
+  uint64_t kmask;        // 2k low bits set
+  uint64_t pmask;        // 2(k-1) low bits set
+  uint32_t n_buckets;
+  uint32_t unit;         // slots per entry (2 = load factor 0.5 in every bucket)
+  uint32_t mmask;        // 2m low bits set
+  uint32_t inv32;        // floor(2^32 / (2w * 256)): fine position -> 32-bit fraction
   int k;
   int canonical;
+  int m;                 // minimizer length (odd, <= 15)
+  int w;                 // minimizer windows in a (k-1)-mer: k - m
 };
+
+// minimizer length / window count for a given k (odd m: an m-mer never equals its own
+// reverse complement, so the strand of a minimizer is always defined)
+__host__ __device__ inline int minimizer_len(int k) {
+  int m = k - 1 < 15 ? k - 1 : 15;
+  if (!(m & 1)) --m;
+  return m < 1 ? 1 : m;
+}
 
 __host__ __device__ inline uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
@@ -72,30 +97,6 @@ __host__ __device__ inline uint64_t revcomp(uint64_t x, int k) {
   return x >> (64 - 2 * k);
 }
 
-struct Group {
-  uint64_t tag;
-  uint32_t flip;   // child base c lives in count[flip ? 3 - c : c]
-};
-
-// Group of the k-mers that have (k-1)-mer P as their prefix.
-__host__ __device__ inline Group group_of_prefix(uint64_t P, int k, int canonical) {
-  Group g;
-  if (!canonical) {
-    g.tag = P << 1;
-    g.flip = 0;
-    return g;
-  }
-  uint64_t R = revcomp(P, k - 1);
-  if (P <= R) {
-    g.tag = P << 1;
-    g.flip = 0;
-  } else {
-    g.tag = (R << 1) | 1;
-    g.flip = 1;
-  }
-  return g;
-}
-
 __host__ __device__ inline uint64_t slot_index(uint64_t tag, uint64_t n_slots) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __umul64hi(mix64(tag), n_slots);
@@ -104,24 +105,146 @@ __host__ __device__ inline uint64_t slot_index(uint64_t tag, uint64_t n_slots) {
 #endif
 }
 
+// Where the group of the k-mers with (k-1)-mer prefix P lives.
+struct Key {
+  uint64_t tag;
+  uint32_t flip;     // child base c lives in count[flip ? 3 - c : c]
+  uint32_t bucket;
+  uint32_t frac;     // order-preserving home position inside the bucket, as a 32-bit fraction
+};
+
+// order hash of a canonical m-mer (a bijection on 32 bits: distinct m-mers never tie)
+__host__ __device__ inline uint32_t mm_order(uint32_t c) { return c * 0x9E3779B1u; }
+// bucket hash, independent of the order hash (a minimizer has a small order hash by construction)
+__host__ __device__ inline uint32_t mm_bucket(uint32_t c) {
+  uint32_t h = c ^ 0x5bd1e995u;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// Window j of P (bases j .. j+m-1): selection key (order hash with the window index in the
+// low 5 bits, so the smallest key is the leftmost smallest minimizer), canonical m-mer, strand.
+__host__ __device__ inline uint32_t window_key(const TableView& t, uint64_t P, uint64_t R, int j,
+                                               uint32_t* canon, uint32_t* strand) {
+  const uint32_t f = (uint32_t)(P >> (2 * (t.w - 1 - j))) & t.mmask;
+  const uint32_t r = (uint32_t)(R >> (2 * j)) & t.mmask;
+  const uint32_t c = f < r ? f : r;
+  *canon = c;
+  *strand = f < r ? 0u : 1u;
+  return (mm_order(c) & ~31u) | (uint32_t)j;
+}
+
+__host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint64_t R, uint32_t c,
+                                           uint32_t s, uint32_t u, Key* key) {
+  if (!t.canonical || P <= R) {
+    key->tag = P << 1;
+    key->flip = 0;
+  } else {
+    key->tag = (R << 1) | 1;
+    key->flip = 1;
+  }
+  key->bucket = (uint32_t)(((uint64_t)mm_bucket(c) * t.n_buckets) >> 32);
+  // walking forward along a strand moves the minimizer one base to the left: u falls, cls rises
+  const uint32_t cls = s * (uint32_t)t.w + ((uint32_t)t.w - 1u - u);
+  const uint32_t jitter = ((uint32_t)key->tag * 0x9E3779B1u) >> 24;
+  key->frac = ((cls << 8) | jitter) * t.inv32;
+}
+
+// One thread computes the whole key (k_seed, table build, batched lookups).
+__host__ __device__ inline Key make_key(const TableView& t, uint64_t P) {
+  const uint64_t R = revcomp(P, t.k - 1);
+  uint32_t best = ~0u, bc = 0, bs = 0;
+  for (int j = 0; j < t.w; ++j) {
+    uint32_t c, s;
+    const uint32_t key = window_key(t, P, R, j, &c, &s);
+    if (key < best) { best = key; bc = c; bs = s; }
+  }
+  Key key;
+  finish_key(t, P, R, bc, bs, best & 31u, &key);
+  return key;
+}
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+// The same key for a wave-uniform P with the windows spread over the lanes (k_dfs: one
+// lookup per walk step, latency matters).  Every lane returns the full key.
+__device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
+  const uint64_t R = revcomp(P, t.k - 1);
+  const int lane = lane_id();
+  uint32_t c = 0, s = 0;
+  uint32_t mine = ~0u;
+  if (lane < t.w) mine = window_key(t, P, R, lane, &c, &s);
+  uint32_t best = ~0u;
+  for (int j = 0; j < t.w; ++j) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+    best = v < best ? v : best;
+  }
+  const int u = (int)(best & 31u);
+  const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, u);
+  const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)s, u);
+  Key key;
+  finish_key(t, P, R, bc, bs, (uint32_t)u, &key);
+  return key;
+}
+
+// Sliding-window form used by k_seed (one lane per base position q of a sequence): the
+// selection key of the m-mer whose 64 leading bits are `bits`, tagged with its position.
+// min over q .. q+w-1 of these keys picks the same window as make_key (smallest order hash,
+// leftmost on ties).
+__device__ inline uint64_t mmer_scan_key(const TableView& t, uint64_t bits, uint32_t q) {
+  const uint32_t f = (uint32_t)(bits >> (64 - 2 * t.m));
+  const uint32_t r = (uint32_t)revcomp(f, t.m);
+  const uint32_t c = f < r ? f : r;
+  return ((uint64_t)(mm_order(c) & ~31u) << 32) | q;
+}
+// Key of P given the window index u chosen by the scan.
+__device__ inline Key key_from_window(const TableView& t, uint64_t P, uint32_t u) {
+  const uint64_t R = revcomp(P, t.k - 1);
+  uint32_t c, s;
+  (void)window_key(t, P, R, (int)u, &c, &s);
+  Key key;
+  finish_key(t, P, R, c, s, u, &key);
+  return key;
+}
+
+struct __attribute__((packed, aligned(4))) DirPair { uint32_t lo, hi; };
+
 __device__ inline uint32_t pick4(uint4 v, uint32_t i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// Counts of the four members of the group `tag` in slot order (zeros if absent), as
-// stored (u16, possibly COUNT_ESCAPE).  One 16-byte load per probe step; *fetches counts
-// the slots read.
-__device__ inline uint4 table_lookup4(const TableView& t, uint64_t tag, uint32_t* fetches) {
-  uint64_t idx = slot_index(tag, t.n_slots);
-  for (uint64_t step = 0; step < t.n_slots; ++step) {
-    const uint4 a = *reinterpret_cast<const uint4*>(t.slots + idx);
+// Linear probing inside the bucket [base, base + S), S > 0, continuing from the slot `a`
+// already loaded from base[idx]: counts of the four members of the group in slot order
+// (zeros if absent), as stored (u16, possibly COUNT_ESCAPE).  One 16-byte load per probe
+// step; *fetches counts the slots read.
+__device__ inline uint4 bucket_resolve(const Key& key, const Slot* base, uint64_t S, uint64_t idx,
+                                       uint4 a, uint32_t* fetches) {
+  for (uint64_t step = 0;;) {
     ++*fetches;
     const uint64_t tg = ((uint64_t)a.y << 32) | a.x;
-    if (tg == tag) return make_uint4(a.z & 0xFFFFu, a.z >> 16, a.w & 0xFFFFu, a.w >> 16);
-    if (tg == EMPTY) break;
-    if (++idx == t.n_slots) idx = 0;
+    if (tg == key.tag) return make_uint4(a.z & 0xFFFFu, a.z >> 16, a.w & 0xFFFFu, a.w >> 16);
+    if (tg == EMPTY || ++step >= S) break;
+    if (++idx == S) idx = 0;
+    a = *reinterpret_cast<const uint4*>(base + idx);
   }
   return make_uint4(0, 0, 0, 0);
+}
+
+__device__ inline uint4 bucket_lookup4(const TableView& t, const Key& key, uint32_t lo, uint32_t hi,
+                                       uint32_t* fetches) {
+  const uint64_t S = (uint64_t)(hi - lo) * t.unit;
+  if (S == 0) return make_uint4(0, 0, 0, 0);
+  const Slot* base = t.slots + (uint64_t)lo * t.unit;
+  const uint64_t idx = __umul64hi((uint64_t)key.frac << 32, S);
+  return bucket_resolve(key, base, S, idx, *reinterpret_cast<const uint4*>(base + idx), fetches);
+}
+
+__device__ inline uint4 table_lookup4(const TableView& t, const Key& key, uint32_t* fetches) {
+  const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + key.bucket);
+  return bucket_lookup4(t, key, d.lo, d.hi, fetches);
 }
 
 // Exact count of a k-mer whose stored count is COUNT_ESCAPE.
@@ -141,11 +264,9 @@ __device__ inline uint32_t overflow_count(const TableView& t, uint64_t kmer) {
   return COUNT_ESCAPE;
 }
 
-// Counts of X[1:]+A, +C, +G, +T (child-base order).
-__device__ inline uint4 forward_children(const TableView& t, uint64_t X, uint32_t* fetches) {
-  Group g = group_of_prefix(X & t.pmask, t.k, t.canonical);
-  uint4 c = table_lookup4(t, g.tag, fetches);
-  if (g.flip) c = make_uint4(c.w, c.z, c.y, c.x);
+// Child-base order + exact values for escaped counts of the group fetched for X[1:].
+__device__ inline uint4 finish_children(const TableView& t, uint64_t X, uint32_t flip, uint4 c) {
+  if (flip) c = make_uint4(c.w, c.z, c.y, c.x);
   if (c.x == COUNT_ESCAPE || c.y == COUNT_ESCAPE || c.z == COUNT_ESCAPE || c.w == COUNT_ESCAPE) {
     const uint64_t base = (X << 2) & t.kmask;
     if (c.x == COUNT_ESCAPE) c.x = overflow_count(t, base | 0);
@@ -156,10 +277,41 @@ __device__ inline uint4 forward_children(const TableView& t, uint64_t X, uint32_
   return c;
 }
 
+// Counts of X[1:]+A, +C, +G, +T (child-base order); g = key of X[1:].
+__device__ inline uint4 forward_children_keyed(const TableView& t, uint64_t X, const Key& g,
+                                               uint32_t* fetches) {
+  return finish_children(t, X, g.flip, table_lookup4(t, g, fetches));
+}
+__device__ inline uint4 forward_children(const TableView& t, uint64_t X, uint32_t* fetches) {
+  return forward_children_keyed(t, X, make_key(t, X & t.pmask), fetches);
+}
+
+// The same for a wave-uniform X (k_dfs): key computed across the lanes, and the directory
+// word of the last bucket kept in registers — consecutive walk steps mostly stay in it.
+struct DirCache { uint32_t bucket, lo, hi; };
+__device__ inline uint4 forward_children_wave(const TableView& t, uint64_t X, DirCache* dc,
+                                              uint32_t* fetches) {
+  const Key g = make_key_wave(t, X & t.pmask);
+  if (g.bucket != dc->bucket) {
+    const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + g.bucket);
+    dc->bucket = g.bucket; dc->lo = d.lo; dc->hi = d.hi;
+  }
+  return finish_children(t, X, g.flip, bucket_lookup4(t, g, dc->lo, dc->hi, fetches));
+}
+
 // Jellyfish.query(X): km/utils/Jellyfish.py:47-53.
+// g = key of X[:-1]
+__device__ inline uint32_t query_one_keyed(const TableView& t, uint64_t X, const Key& g,
+                                           uint32_t* fetches) {
+  uint4 c = table_lookup4(t, g, fetches);
+  uint32_t s = (uint32_t)(X & 3);
+  uint32_t v = pick4(c, g.flip ? 3 - s : s);
+  if (v == COUNT_ESCAPE) v = overflow_count(t, X);
+  return v;
+}
 __device__ inline uint32_t query_one(const TableView& t, uint64_t X, uint32_t* fetches) {
-  Group g = group_of_prefix(X >> 2, t.k, t.canonical);
-  uint4 c = table_lookup4(t, g.tag, fetches);
+  const Key g = make_key(t, X >> 2);
+  uint4 c = table_lookup4(t, g, fetches);
   uint32_t s = (uint32_t)(X & 3);
   uint32_t v = pick4(c, g.flip ? 3 - s : s);
   if (v == COUNT_ESCAPE) v = overflow_count(t, X);
@@ -181,7 +333,5 @@ __device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) {
   m |= ((double)c.w >= thr) ? 8u : 0u;
   return m;
 }
-
-__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace kmd

@@ -87,6 +87,9 @@ struct kmjf {
   int device = -1;
   Slot* d_slots = nullptr;
   uint64_t n_slots = 0;
+  uint32_t* d_dir = nullptr;     // [n_buckets + 1] (+ padding) exclusive prefix of bucket sizes
+  uint32_t n_buckets = 0;
+  uint32_t unit = 2;
   OvfSlot* d_ovf = nullptr;
   uint64_t n_ovf = 0;
   uint64_t n_groups = 0;
@@ -97,13 +100,20 @@ static uint64_t mask_bits(int nbases) { return nbases >= 32 ? ~0ull : ((1ull << 
 static TableView view_of(const kmjf* h) {
   TableView t;
   t.slots = h->d_slots;
+  t.dir = h->d_dir;
   t.n_slots = h->n_slots;
   t.ovf = h->d_ovf;
   t.n_ovf = h->n_ovf;
   t.kmask = mask_bits(h->k);
   t.pmask = mask_bits(h->k - 1);
+  t.n_buckets = h->n_buckets;
+  t.unit = h->unit;
   t.k = h->k;
   t.canonical = h->canonical;
+  t.m = minimizer_len(h->k);
+  t.w = h->k - t.m;
+  t.mmask = (uint32_t)mask_bits(t.m);
+  t.inv32 = (uint32_t)((1ull << 32) / ((uint64_t)2 * t.w * 256));
   return t;
 }
 
@@ -159,8 +169,11 @@ static void free_table(kmjf* h) {
     if (h->d_ovf) (void)hipFree(h->d_ovf);
     h->d_ovf = nullptr;
     h->n_ovf = 0;
+    if (h->d_dir) (void)hipFree(h->d_dir);
+    h->d_dir = nullptr;
   }
   h->n_slots = h->n_groups = 0;
+  h->n_buckets = 0;
   h->device = -1;
 }
 
@@ -178,7 +191,8 @@ extern "C" int kmjf_info(const kmjf_t* h, kmjf_info_t* info) {
   info->n_records = h->n_records;
   info->n_slots = h->n_slots;
   info->n_groups = h->n_groups;
-  info->table_bytes = h->n_slots * sizeof(Slot) + h->n_ovf * sizeof(OvfSlot);
+  info->table_bytes = h->n_slots * sizeof(Slot) + h->n_ovf * sizeof(OvfSlot) +
+                      (h->d_dir ? ((uint64_t)h->n_buckets + 1) * 4 : 0);
   info->device = h->device;
   info->reserved = 0;
   return KM_OK;
@@ -200,52 +214,94 @@ static int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
+// Build: count entries per minimizer bucket -> exclusive scan (= the directory) -> allocate
+// `unit` slots per entry -> insert.  All on the device, from device-resident records.
 extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_keys,
                                        const uint32_t* d_counts, uint64_t n, void* stream) {
   if (!h || (n && (!d_keys || !d_counts))) return fail(KM_E_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   free_table(h);
   HIPCHK(hipSetDevice(device));
-  // every record enters at most two groups; keep the load factor <= 0.5
-  uint64_t entries = (h->canonical ? 2 : 1) * n;
-  // KM_TABLE_LOAD: target load factor of the HBM table (HBM capacity is plentiful)
-  double load = 0.5;
-  if (const char* lf = getenv("KM_TABLE_LOAD")) { double v = atof(lf); if (v >= 0.05 && v <= 0.9) load = v; }
-  uint64_t n_slots = std::max<uint64_t>(1024, (uint64_t)((double)entries / load) + 1);
-  n_slots = (n_slots + 63) & ~63ull;
-  Slot* slots = nullptr;
-  HIPCHK(hipMalloc((void**)&slots, n_slots * sizeof(Slot)));
+  // every record enters at most two groups
+  const uint64_t max_entries = (h->canonical ? 2 : 1) * n;
+  if (max_entries >= (1ull << 32)) return fail(KM_E_CAPACITY, "more than 2^32 table entries");
+  // KM_TABLE_LOAD: load factor inside every bucket (HBM capacity is plentiful): unit = 1/load
+  uint32_t unit = 2;
+  if (const char* lf = getenv("KM_TABLE_LOAD")) {
+    double v = atof(lf);
+    if (v >= 0.05 && v <= 0.5) unit = (uint32_t)(1.0 / v + 0.5);
+  }
+  // KM_DIR_LOG2: log2 of the bucket count (default: about one bucket per 4 entries)
+  uint32_t n_buckets = 1024;
+  while ((uint64_t)n_buckets * 4 < max_entries && n_buckets < (1u << 30)) n_buckets <<= 1;
+  if (const char* dl = getenv("KM_DIR_LOG2")) { int v = atoi(dl); if (v >= 4 && v <= 30) n_buckets = 1u << v; }
+  const uint32_t n_chunks = (uint32_t)(((uint64_t)n_buckets + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  uint32_t* dir = nullptr;
+  uint32_t* sums = nullptr;
   unsigned long long* d_meta = nullptr;   // [0] groups, [1] error flag (low 32 bits), [2] big counts
-  hipError_t e = hipMalloc((void**)&d_meta, 32);
-  if (e != hipSuccess) { (void)hipFree(slots); return fail(KM_E_NOMEM, "hipMalloc failed"); }
+  Slot* slots = nullptr;
+  OvfSlot* ovf = nullptr;
+  auto bail = [&](int code, const char* what, hipError_t e) {
+    if (dir) (void)hipFree(dir);
+    if (sums) (void)hipFree(sums);
+    if (d_meta) (void)hipFree(d_meta);
+    if (slots) (void)hipFree(slots);
+    if (ovf) (void)hipFree(ovf);
+    return fail(code, "%s: %s", what, hipGetErrorString(e));
+  };
+  hipError_t e = hipMalloc((void**)&dir, (uint64_t)n_chunks * SCAN_CHUNK * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&sums, (uint64_t)n_chunks * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_meta, 32);
+  if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
+  (void)hipMemsetAsync(dir, 0, (uint64_t)n_chunks * SCAN_CHUNK * 4, st);
   (void)hipMemsetAsync(d_meta, 0, 32, st);
-  // side table for the (rare) counts that do not fit 16 bits
+
+  kmjf shape;               // a view with the geometry only, for the build kernels
+  shape.k = h->k; shape.canonical = h->canonical;
+  shape.d_dir = dir; shape.n_buckets = n_buckets; shape.unit = unit;
+  TableView tv = view_of(&shape);
+  shape.d_dir = nullptr;    // not owned
+
   unsigned long long n_big = 0;
+  uint32_t entries = 0;
   if (n) {
     hipLaunchKernelGGL(k_count_big, dim3(grid_for(n, 256)), dim3(256), 0, st, d_counts, n, d_meta + 2);
-    e = hipMemcpyAsync(&n_big, d_meta + 2, 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(slots); (void)hipFree(d_meta); return fail(KM_E_HIP, "count pass failed: %s", hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_dir_count, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, d_keys, d_counts, n, dir);
   }
-  OvfSlot* ovf = nullptr;
-  uint64_t n_ovf = n_big ? (n_big * 2 + 64) : 0;
+  hipLaunchKernelGGL(k_scan_reduce, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, dir, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, n_chunks);
+  hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, dir, sums);
+  e = hipMemcpyAsync(&n_big, d_meta + 2, 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(&entries, dir + n_buckets, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return bail(KM_E_HIP, "count pass failed", e);
+
+  const uint64_t n_slots = std::max<uint64_t>(64, (uint64_t)entries * unit);
+  e = hipMalloc((void**)&slots, n_slots * sizeof(Slot));
+  if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
+  // side table for the (rare) counts that do not fit 16 bits
+  const uint64_t n_ovf = n_big ? (n_big * 2 + 64) : 0;
   if (n_ovf) {
     e = hipMalloc((void**)&ovf, n_ovf * sizeof(OvfSlot));
-    if (e != hipSuccess) { (void)hipFree(slots); (void)hipFree(d_meta); return fail(KM_E_NOMEM, "hipMalloc failed"); }
+    if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
     (void)hipMemsetAsync(ovf, 0, n_ovf * sizeof(OvfSlot), st);
   }
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
   if (n)
-    hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, slots, n_slots,
-                       d_keys, d_counts, n, h->k, h->canonical, ovf, n_ovf, d_meta,
+    hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, slots,
+                       d_keys, d_counts, n, ovf, n_ovf, d_meta,
                        reinterpret_cast<unsigned int*>(d_meta + 1));
   unsigned long long meta[2] = {0, 0};
   e = hipMemcpyAsync(meta, d_meta, 16, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return bail(KM_E_HIP, "table build failed", e);
+  if (meta[1] & 0xFFFFFFFFull) return bail(KM_E_HIP, "table build overflowed", hipSuccess);
+  (void)hipFree(sums);
   (void)hipFree(d_meta);
-  if (e != hipSuccess) { (void)hipFree(slots); if (ovf) (void)hipFree(ovf); return fail(KM_E_HIP, "table build failed: %s", hipGetErrorString(e)); }
-  if (meta[1] & 0xFFFFFFFFull) { (void)hipFree(slots); if (ovf) (void)hipFree(ovf); return fail(KM_E_HIP, "table build overflowed"); }
   h->d_slots = slots;
+  h->d_dir = dir;
+  h->n_buckets = n_buckets;
+  h->unit = unit;
   h->d_ovf = ovf;
   h->n_ovf = n_ovf;
   h->n_slots = n_slots;
@@ -803,7 +859,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
     if (!capturing) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
-      hipLaunchKernelGGL(k_seed, dim3(b->n_items), dim3(SEED_BLOCK), 0, st, wa);
+      hipLaunchKernelGGL(k_seed<SEED_NS>, dim3((b->n_items + SEED_NS - 1) / SEED_NS), dim3(SEED_BLOCK), 0, st, wa);
     if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
     if (b->fast_ok) {
       // unflagged targets are final after k_seed: their pure-chain check runs on the side

@@ -23,24 +23,123 @@ __global__ void k_count_big(const uint32_t* counts, uint64_t n, unsigned long lo
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
-// One record per thread: enter the k-mer under the group of each orientation.
-// err[0] != 0 on return means the table was too small (never with our sizing).
-__global__ void k_table_insert(Slot* slots, uint64_t n_slots, const uint64_t* keys,
-                               const uint32_t* counts, uint64_t n, int k, int canonical,
-                               OvfSlot* ovf, uint64_t n_ovf,
+// Orientations under which a stored record is entered: 0 (a non-canonical key in a canonical
+// database is unreachable by query(), as in the reference), 1 (palindrome / non-canonical
+// database) or 2.
+__device__ inline int record_orientations(uint64_t K, int k, int canonical, uint64_t* R) {
+  *R = K;
+  if (!canonical) return 1;
+  *R = revcomp(K, k);
+  if (*R < K) return 0;
+  return (*R == K) ? 1 : 2;
+}
+
+// Pass 1 of the build: entries per minimizer bucket.
+__global__ void k_dir_count(TableView t, const uint64_t* keys, const uint32_t* counts, uint64_t n,
+                            uint32_t* cnt) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t K = keys[i];
+    if (counts[i] == 0) continue;
+    uint64_t R;
+    const int n_or = record_orientations(K, t.k, t.canonical, &R);
+    for (int o = 0; o < n_or; ++o) {
+      const Key key = make_key(t, (o ? R : K) >> 2);
+      atomicAdd(&cnt[key.bucket], 1u);
+    }
+  }
+}
+
+// Exclusive prefix sum of the bucket counts, in place (three passes over chunks of
+// SCAN_CHUNK words; the array is zero-padded to a whole number of chunks).
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 16;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wave_sum[SCAN_THREADS / 64];
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  uint32_t inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = __shfl_up(inc, o);
+    if (lane >= o) inc += x;
+  }
+  if (lane == 63) wave_sum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (int q = 0; q < SCAN_THREADS / 64; ++q) {
+    const uint32_t ws = wave_sum[q];
+    if (q < wave) before += ws;
+    all += ws;
+  }
+  __syncthreads();
+  *total = all;
+  return before + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* data, uint32_t* sums) {
+  const uint4* p = reinterpret_cast<const uint4*>(data + (uint64_t)blockIdx.x * SCAN_CHUNK);
+  uint32_t v = 0;
+  for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
+    const uint4 x = p[q * SCAN_THREADS + threadIdx.x];
+    v += x.x + x.y + x.z + x.w;
+  }
+  uint32_t total;
+  (void)block_exclusive_scan(v, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// one block: sums[0..n) -> exclusive prefix, in place
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(uint32_t* sums, uint32_t n) {
+  const uint32_t per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+  const uint32_t lo = threadIdx.x * per;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  uint32_t v = 0;
+  for (uint32_t i = lo; i < hi; ++i) v += sums[i];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(v, &total);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t x = sums[i];
+    sums[i] = run;
+    run += x;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* data, const uint32_t* sums) {
+  uint4* p = reinterpret_cast<uint4*>(data + (uint64_t)blockIdx.x * SCAN_CHUNK) +
+             threadIdx.x * (SCAN_PER_THREAD / 4);
+  uint4 x[SCAN_PER_THREAD / 4];
+  uint32_t v = 0;
+  for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
+    x[q] = p[q];
+    v += x[q].x + x[q].y + x[q].z + x[q].w;
+  }
+  uint32_t total;
+  uint32_t run = sums[blockIdx.x] + block_exclusive_scan(v, &total);
+  for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
+    uint4 o;
+    o.x = run; run += x[q].x;
+    o.y = run; run += x[q].y;
+    o.z = run; run += x[q].z;
+    o.w = run; run += x[q].w;
+    p[q] = o;
+  }
+}
+
+// Pass 2: one record per thread, entered under the group of each orientation, by linear
+// probing from its order-preserving home inside its bucket.  err[0] != 0 on return means a
+// bucket was too small (cannot happen: buckets are sized from the same entry counts).
+__global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
+                               const uint32_t* counts, uint64_t n, OvfSlot* ovf, uint64_t n_ovf,
                                unsigned long long* n_groups, unsigned int* err) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t K = keys[i];
     const uint32_t v = counts[i];
     if (v == 0) continue;
-    uint64_t R = K;
-    int n_or = 1;
-    if (canonical) {
-      R = revcomp(K, k);
-      if (R < K) continue;            // not canonical: unreachable by query(), as in the reference
-      n_or = (R == K) ? 1 : 2;
-    }
+    uint64_t R;
+    const int n_or = record_orientations(K, t.k, t.canonical, &R);
+    if (n_or == 0) continue;
     if (v >= COUNT_ESCAPE) {
       // exact value to the side table (keyed by the k-mer as stored)
       bool placed = false;
@@ -53,21 +152,24 @@ __global__ void k_table_insert(Slot* slots, uint64_t n_slots, const uint64_t* ke
     }
     for (int o = 0; o < n_or; ++o) {
       const uint64_t O = o ? R : K;
-      Group g = group_of_prefix(O >> 2, k, canonical);
+      const Key g = make_key(t, O >> 2);
       uint32_t s = (uint32_t)(O & 3);
       if (g.flip) s = 3 - s;
-      uint64_t idx = slot_index(g.tag, n_slots);
+      const uint32_t lo = t.dir[g.bucket], hi = t.dir[g.bucket + 1];
+      const uint64_t S = (uint64_t)(hi - lo) * t.unit;
+      Slot* base = slots + (uint64_t)lo * t.unit;
+      uint64_t idx = S ? __umul64hi((uint64_t)g.frac << 32, S) : 0;
       bool done = false;
-      for (uint64_t step = 0; step < n_slots; ++step) {
-        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[idx].tag),
+      for (uint64_t step = 0; step < S; ++step) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&base[idx].tag),
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
         if (old == EMPTY) atomicAdd(n_groups, 1ull);
         if (old == EMPTY || old == g.tag) {
-          slots[idx].c[s] = (uint16_t)(v >= COUNT_ESCAPE ? COUNT_ESCAPE : v);
+          base[idx].c[s] = (uint16_t)(v >= COUNT_ESCAPE ? COUNT_ESCAPE : v);
           done = true;
           break;
         }
-        if (++idx == n_slots) idx = 0;
+        if (++idx == S) idx = 0;
       }
       if (!done) atomicExch(err, 1u);
     }

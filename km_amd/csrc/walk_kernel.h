@@ -237,55 +237,140 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
 }
 
 // ---------------------------------------------------------------------------- k_seed
+constexpr int SEED_NS = 2;   // item records per k_seed block
+// One lane per target k-mer ("seed"): its count, its get_child and the trivial / flagged
+// decision.  Every block works on NS item records at once and keeps the NS independent
+// chains  bases -> minimizer -> directory word -> slot  in flight together: the kernel is
+// bound by the latency of that chain, not by HBM bandwidth.
+template <int NS>
 __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   static_assert(SEED_BLOCK == 256, "the item record holds 12 words = 256 seeds + k - 1 + 1 bases");
-  const uint64_t* rec = a.items + 16ull * blockIdx.x;
-  const uint64_t h0 = rec[0], h1 = rec[1];
-  if ((uint32_t)(h1 >> 32) == 0u) return;                  // target not walkable (status != OK)
+  // per wave: two ping-pong rows of 96 sliding-window keys (64 own positions + up to w beyond)
+  __shared__ uint64_t win[SEED_BLOCK / 64][2][96];
   const TableView tab = a.tab;
   const int k = tab.k;
-  const uint32_t t = (uint32_t)h0;
-  const uint32_t start = (uint32_t)(h0 >> 32);
-  const uint32_t n_ref = (uint32_t)h1;
-  const uint32_t i = start + threadIdx.x;
-  unsigned long long probes_l = 0;
-  uint32_t fetch_l = 0;
-  if (i < n_ref) {
-    const uint64_t nb = rec[2];
-    const uint32_t w = threadIdx.x >> 5, sh = (threadIdx.x & 31) * 2;   // start is a multiple of 256
-    const uint64_t hi = rec[4 + w], lo = rec[5 + w];
-    const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
-    const uint64_t X = x >> (64 - 2 * k);
-    a.node_kmer[nb + i] = X;
-    const uint4 c4 = forward_children(tab, X, &fetch_l);
-    uint32_t nextb = 4;
-    if (i + 1 < n_ref) {
-      const uint32_t p = threadIdx.x + (uint32_t)k;       // last base of ref[i+1], item-relative
-      nextb = (uint32_t)(rec[4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
-      a.node_cnt[nb + i + 1] = pick4(c4, nextb);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t (*buf)[96] = win[threadIdx.x >> 6];
+  const uint32_t W = (uint32_t)tab.w;
+  const uint32_t K = 1u << (31 - __clz((int)W));           // largest power of two <= w
+
+  const uint64_t* rec[NS];
+  bool live[NS];
+  uint32_t tgt[NS], idx0[NS], n_ref[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const uint32_t item = blockIdx.x * NS + s;
+    live[s] = item < a.n_items;
+    rec[s] = a.items + 16ull * (live[s] ? item : 0u);
+    const uint64_t h0 = rec[s][0], h1 = rec[s][1];
+    live[s] = live[s] && (uint32_t)(h1 >> 32) != 0u;       // else: target not walkable (status != OK)
+    tgt[s] = (uint32_t)h0;
+    idx0[s] = (uint32_t)(h0 >> 32) + threadIdx.x;          // the first seed of an item is a multiple of 256
+    n_ref[s] = (uint32_t)h1;
+  }
+  // 64 bits of the target starting at item-relative base q
+  auto bits_at = [&](const uint64_t* r, uint32_t q) -> uint64_t {
+    const uint32_t w = q >> 5, sh = (q & 31) * 2;
+    const uint64_t hi = r[4 + w], lo = r[5 + w];
+    return sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+  };
+  uint64_t x[NS], xe[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    x[s] = bits_at(rec[s], threadIdx.x);
+    xe[s] = lane < W ? bits_at(rec[s], (threadIdx.x & ~63u) + 64 + lane) : 0ull;
+  }
+
+  // ---- minimizers of all (k-1)-mers of this wave's 64 seeds in one sliding-window scan:
+  // lane l owns the m-mer at wave-relative base q = l, lanes < w also q = 64 + l; the
+  // minimizer of the (k-1)-mer starting at base q is min over q .. q+w-1 (log-step doubling).
+  uint32_t u_child[NS], u_first[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    buf[0][lane] = mmer_scan_key(tab, x[s], lane);
+    if (lane < 32) buf[0][64 + lane] = lane < W ? mmer_scan_key(tab, xe[s], 64 + lane) : ~0ull;
+    uint32_t src = 0;
+    for (uint32_t d = 1; d < K; d <<= 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint64_t a0 = buf[src][lane], a1 = buf[src][lane + d];
+      buf[src ^ 1][lane] = a0 < a1 ? a0 : a1;
+      if (lane < 32) {
+        const uint32_t q = 64 + lane;
+        const uint64_t b0 = buf[src][q], b1 = q + d < 96 ? buf[src][q + d] : ~0ull;
+        buf[src ^ 1][q] = b0 < b1 ? b0 : b1;
+      }
+      src ^= 1;
     }
-    if (i == 0) a.node_cnt[nb] = query_one(tab, X, &fetch_l);
-    probes_l = 1;                                          // node_data[s] = jf.query(s)
-    if (a.max_stack > 0) {
-      const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
-      const bool trivial = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
-      if (trivial) {
-        probes_l += 4 + (mask ? 1 : 0);                    // get_child + re-query of [seed]
-      } else {
-        atomicOr(&a.flagbits[rec[3] + (i >> 5)], 1u << (i & 31));
-        if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint64_t m0 = buf[src][lane + 1], m1 = buf[src][lane + 1 + W - K];
+    u_child[s] = (uint32_t)(m0 < m1 ? m0 : m1) - (lane + 1);  // window of X[1:] (starts at base q = l+1)
+    const uint64_t f0 = buf[src][0], f1 = buf[src][W - K];
+    u_first[s] = (uint32_t)(f0 < f1 ? f0 : f1);                // window of X[:-1] of lane 0 (base 0)
+  }
+
+  // ---- keys, directory words, first probes: all NS loads of a stage are issued together
+  uint64_t X[NS], S[NS], pos[NS];
+  Key g[NS];
+  DirPair dw[NS];
+  const Slot* base[NS];
+  uint4 first[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    X[s] = x[s] >> (64 - 2 * k);
+    g[s] = key_from_window(tab, X[s] & tab.pmask, (a.dbg & 0x10u) ? 0u : u_child[s]);
+    dw[s] = *reinterpret_cast<const DirPair*>(tab.dir + g[s].bucket);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    S[s] = (uint64_t)(dw[s].hi - dw[s].lo) * tab.unit;
+    base[s] = tab.slots + (uint64_t)dw[s].lo * tab.unit;
+    pos[s] = S[s] ? __umul64hi((uint64_t)g[s].frac << 32, S[s]) : 0;
+    first[s] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    if (S[s]) first[s] = *reinterpret_cast<const uint4*>(base[s] + pos[s]);
+  }
+
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (!live[s]) continue;                                // block-uniform
+    const uint32_t i = idx0[s], t = tgt[s];
+    uint32_t fetch_l = 0;
+    bool valid = false, triv = false, triv_child = false;
+    if (i < n_ref[s]) {
+      valid = true;
+      const uint64_t nb = rec[s][2];
+      a.node_kmer[nb + i] = X[s];
+      uint4 c4 = make_uint4(0, 0, 0, 0);
+      if (S[s]) c4 = bucket_resolve(g[s], base[s], S[s], pos[s], first[s], &fetch_l);
+      c4 = finish_children(tab, X[s], g[s].flip, c4);
+      uint32_t nextb = 4;
+      if (i + 1 < n_ref[s]) {
+        const uint32_t p = threadIdx.x + (uint32_t)k;     // last base of ref[i+1], item-relative
+        nextb = (uint32_t)(rec[s][4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+        a.node_cnt[nb + i + 1] = pick4(c4, nextb);
+      }
+      if (i == 0)
+        a.node_cnt[nb] = query_one_keyed(tab, X[s], key_from_window(tab, X[s] >> 2, u_first[s]), &fetch_l);
+      if (a.max_stack > 0) {
+        const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
+        triv = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
+        triv_child = triv && mask != 0;
+        if (!triv) {
+          atomicOr(&a.flagbits[rec[s][3] + (i >> 5)], 1u << (i & 31));
+          if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
+        }
       }
     }
-  }
-  // one atomic per wave for the per-target counters
-  unsigned long long f64 = fetch_l;
-  for (int o = 32; o > 0; o >>= 1) {
-    probes_l += __shfl_xor(probes_l, o);
-    f64 += __shfl_xor(f64, o);
-  }
-  if ((threadIdx.x & 63) == 0 && probes_l) {
-    atomicAdd(&a.probes[t], probes_l);
-    atomicAdd(&a.fetches[t], f64);
+    // one atomic per wave for the per-target counters.  Logical probes per seed:
+    // node_data[s] = jf.query(s) (1); for a trivial seed also get_child (4) and the
+    // re-query of [seed] when it has a child (1)
+    const unsigned long long probes_w = (unsigned long long)__popcll(__ballot(valid)) +
+                                        4ull * __popcll(__ballot(triv)) + __popcll(__ballot(triv_child));
+    for (int o = 32; o > 0; o >>= 1) fetch_l += __shfl_xor(fetch_l, o);
+    if (lane == 0 && probes_w) {
+      atomicAdd(&a.probes[t], probes_w);
+      atomicAdd(&a.fetches[t], (unsigned long long)fetch_l);
+    }
   }
 }
 
@@ -365,6 +450,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
 
   uint32_t st = T_OK;
   uint32_t n_nodes = n_ref;
+  DirCache dcache = {~0u, 0u, 0u};
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
@@ -393,7 +479,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           if (need_expand) {
             need_expand = false;
             if (n_nodes > a.max_node) { st = T_NODE_LIMIT; break; }
-            c4 = forward_children(tab, cur, &fetch_u);
+            c4 = forward_children_wave(tab, cur, &dcache, &fetch_u);
             probes_u += 4;
             mask = child_mask(c4, a.ratio, a.n_cutoff);
             brk = parent_brk;
