@@ -91,6 +91,9 @@ def main():
                     help="targets for the end-to-end (strings in -> TSV rows out) measurement")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay each step as one captured hipGraph (measured: no gain, GPU-bound)")
+    ap.add_argument("--walk-only", action="store_true", help="time the walk stage only (ablations)")
+    ap.add_argument("--cache", default="", help="directory to keep the generated workload in "
+                    "(re-used by later invocations with the same sizes)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
@@ -125,8 +128,16 @@ def main():
     t_gen = time.perf_counter()
     case = None
     if rank == 0:
-        case = synth.make_case(n_targets=T * world, length=args.length, k=K, n_keys=args.keys,
-                               seed=synth.HEADLINE_SEED, exact_pad=False)
+        tag = "%s/case_%d_%d_%d" % (args.cache, T * world, args.length, args.keys)
+        if args.cache and os.path.exists(tag + "_keys.npy"):
+            case = {f: np.load("%s_%s.npy" % (tag, f)) for f in ("keys", "counts", "targets")}
+        else:
+            case = synth.make_case(n_targets=T * world, length=args.length, k=K, n_keys=args.keys,
+                                   seed=synth.HEADLINE_SEED, exact_pad=False)
+            if args.cache:
+                os.makedirs(args.cache, exist_ok=True)
+                for f in ("keys", "counts", "targets"):
+                    np.save("%s_%s.npy" % (tag, f), case[f])
     t_gen = time.perf_counter() - t_gen
 
     # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------
@@ -170,7 +181,7 @@ def main():
         batches.append(bq)
     torch.cuda.synchronize()
     batch = batches[0]
-    both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    both = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH)
     replay = (both | kmlib.KM_RUN_HIPGRAPH) if args.hipgraph else both
 
     # ---- warm-up ---------------------------------------------------------------------------

@@ -187,6 +187,12 @@ int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
  * [3] the k_seed kernel alone. */
 int km_batch_timings(km_batch_t* b, float* ms4);
 
+/* Diagnostics: with KM_SEED_STAMPS set in the environment k_seed records, per wave, eight
+ * s_memtime stamps (start, header, bases, minimizer scan, directory words, slots, resolved,
+ * end), two s_memrealtime stamps (start, end) and the HW_ID placement, 16 words per wave.
+ * dst == NULL only reports the size.  Stamped runs are slower; never use them for timing. */
+int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_words, uint64_t* n_words);
+
 /* ---- misc ---------------------------------------------------------------- */
 const char* km_strerror(int code);
 const char* km_last_error(void);   /* thread-local detail of the last failure */

@@ -20,15 +20,18 @@
 //
 //  (2) slots are grouped into variable-size buckets by the MINIMIZER of P (the m-mer of
 //      P, m = 15 for k = 31, whose canonical form has the smallest order hash):
-//        dir[b] .. dir[b+1]  = the entries of bucket b (an exclusive prefix sum, u32),
-//        bucket b owns the slots [unit*dir[b], unit*dir[b+1])  (unit = 2: load <= 0.5).
+//        bucket b owns the slots [2*dir[b], 2*dir[b+1])   (dir = exclusive prefix sum, u32)
 //      Consecutive (k-1)-mers of a sequence share their minimizer for ~(w+1)/2 steps
-//      (w = k-m windows), i.e. they live in the same bucket.  Inside the bucket the home
-//      position is ORDER PRESERVING in (strand of the minimizer, its offset in P): the
-//      next (k-1)-mer of a walk sits in the next slot (linear probing resolves clashes),
-//      so ~8 consecutive lookups of a target share one or two 128-byte HBM lines and one
-//      directory word instead of touching 8 random lines.  Because every bucket is sized
-//      from its own entry count, a heavy minimizer cannot overfill its neighbourhood.
+//      (w = k-m windows), i.e. they live in the same bucket.  Every bucket is sized from
+//      its own entry count, so a heavy minimizer cannot overfill its neighbourhood.
+//      * a bucket with fewer than ~w entries is a small hash table (2 slots per entry) with
+//        an order-preserving home position;
+//      * a larger one ("class mode", S = q * NC slots, NC = the power of two >= 2w, q >= 2)
+//        gives each of the 2w classes (strand of the minimizer, its offset in P) its own q
+//        slots: the (k-1)-mers of one super-k-mer fall into consecutive classes and never
+//        collide with each other, so a lookup finds its slot in the aligned pair it reads
+//        first and the next (k-1)-mer of a walk sits q slots further in the same HBM lines.
+//      A wave waits for its slowest lane: bounding the probe length matters more than its mean.
 //
 // Counts are stored as u16; a count >= 65535 is stored as 0xFFFF and its exact value
 // lives in a small side table keyed by the canonical k-mer (OvfSlot), consulted only then.
@@ -57,13 +60,15 @@ struct __attribute__((aligned(16))) OvfSlot {
 struct TableView {
   const Slot* slots;
   const uint32_t* dir;   // [n_buckets + 1] exclusive prefix sum of entries per bucket
-  uint64_t n_slots;      // unit * dir[n_buckets]
+  uint64_t n_slots;      // 2 * dir[n_buckets]
   const OvfSlot* ovf;
   uint64_t n_ovf;
   uint64_t kmask;        // 2k low bits set
   uint64_t pmask;        // 2(k-1) low bits set
   uint32_t n_buckets;
-  uint32_t unit;         // slots per entry (2 = load factor 0.5 in every bucket)
+  uint32_t unit;         // slots per entry when sizing a bucket (2 = load factor <= 0.5)
+  uint32_t cshift;       // log2(NC), NC = power of two >= 2w: class-mode buckets hold q * NC slots
+  uint32_t max_probe;    // every stored key sits within this many slots of its home (2: the home pair)
   uint32_t mmask;        // 2m low bits set
   uint32_t inv32;        // floor(2^32 / (2w * 256)): fine position -> 32-bit fraction
   int k;
@@ -90,11 +95,28 @@ __host__ __device__ inline uint64_t mix64(uint64_t x) {
 }
 
 __host__ __device__ inline uint64_t revcomp(uint64_t x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // bit reversal reverses the base order and swaps the two bits of every base; swap them back
+  uint64_t y = __brevll(~x);
+  y = ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+  return y >> (64 - 2 * k);
+#else
   x = ~x;
   x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
   x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
   x = __builtin_bswap64(x);
   return x >> (64 - 2 * k);
+#endif
+}
+// the same for an m-mer held in 32 bits (m <= 16)
+__host__ __device__ inline uint32_t revcomp32(uint32_t x, int m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t y = __brev(~x);
+  y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+  return y >> (32 - 2 * m);
+#else
+  return (uint32_t)revcomp((uint64_t)x, m);
+#endif
 }
 
 __host__ __device__ inline uint64_t slot_index(uint64_t tag, uint64_t n_slots) {
@@ -110,7 +132,9 @@ struct Key {
   uint64_t tag;
   uint32_t flip;     // child base c lives in count[flip ? 3 - c : c]
   uint32_t bucket;
-  uint32_t frac;     // order-preserving home position inside the bucket, as a 32-bit fraction
+  uint32_t frac;     // small buckets: order-preserving home position as a 32-bit fraction
+  uint32_t cls;      // class-mode buckets: class in [0, 2w)
+  uint32_t hsub;     // class-mode buckets: hash choosing the slot pair inside the class
 };
 
 // order hash of a canonical m-mer (a bijection on 32 bits: distinct m-mers never tie)
@@ -125,8 +149,9 @@ __host__ __device__ inline uint32_t mm_bucket(uint32_t c) {
   return h;
 }
 
-// Window j of P (bases j .. j+m-1): selection key (order hash with the window index in the
-// low 5 bits, so the smallest key is the leftmost smallest minimizer), canonical m-mer, strand.
+// Window j of P (bases j .. j+m-1): selection key (25 bits of order hash above 7 bits of
+// position, so the smallest key is the leftmost smallest minimizer), canonical m-mer, strand.
+constexpr uint32_t SEL_POS = 127u;
 __host__ __device__ inline uint32_t window_key(const TableView& t, uint64_t P, uint64_t R, int j,
                                                uint32_t* canon, uint32_t* strand) {
   const uint32_t f = (uint32_t)(P >> (2 * (t.w - 1 - j))) & t.mmask;
@@ -134,7 +159,7 @@ __host__ __device__ inline uint32_t window_key(const TableView& t, uint64_t P, u
   const uint32_t c = f < r ? f : r;
   *canon = c;
   *strand = f < r ? 0u : 1u;
-  return (mm_order(c) & ~31u) | (uint32_t)j;
+  return (mm_order(c) & ~SEL_POS) | (uint32_t)j;
 }
 
 __host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint64_t R, uint32_t c,
@@ -149,8 +174,10 @@ __host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint6
   key->bucket = (uint32_t)(((uint64_t)mm_bucket(c) * t.n_buckets) >> 32);
   // walking forward along a strand moves the minimizer one base to the left: u falls, cls rises
   const uint32_t cls = s * (uint32_t)t.w + ((uint32_t)t.w - 1u - u);
-  const uint32_t jitter = ((uint32_t)key->tag * 0x9E3779B1u) >> 24;
-  key->frac = ((cls << 8) | jitter) * t.inv32;
+  const uint32_t h = (uint32_t)key->tag * 0x9E3779B1u;
+  key->frac = ((cls << 8) | (h >> 24)) * t.inv32;
+  key->cls = cls;
+  key->hsub = h;
 }
 
 // One thread computes the whole key (k_seed, table build, batched lookups).
@@ -163,7 +190,7 @@ __host__ __device__ inline Key make_key(const TableView& t, uint64_t P) {
     if (key < best) { best = key; bc = c; bs = s; }
   }
   Key key;
-  finish_key(t, P, R, bc, bs, best & 31u, &key);
+  finish_key(t, P, R, bc, bs, best & SEL_POS, &key);
   return key;
 }
 
@@ -182,7 +209,7 @@ __device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
     const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
     best = v < best ? v : best;
   }
-  const int u = (int)(best & 31u);
+  const int u = (int)(best & SEL_POS);
   const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, u);
   const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)s, u);
   Key key;
@@ -190,15 +217,15 @@ __device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
   return key;
 }
 
-// Sliding-window form used by k_seed (one lane per base position q of a sequence): the
+// Sliding-window form used by k_seed (one lane per base position q < 128 of a sequence): the
 // selection key of the m-mer whose 64 leading bits are `bits`, tagged with its position.
 // min over q .. q+w-1 of these keys picks the same window as make_key (smallest order hash,
 // leftmost on ties).
-__device__ inline uint64_t mmer_scan_key(const TableView& t, uint64_t bits, uint32_t q) {
+__device__ inline uint32_t mmer_scan_key(const TableView& t, uint64_t bits, uint32_t q) {
   const uint32_t f = (uint32_t)(bits >> (64 - 2 * t.m));
-  const uint32_t r = (uint32_t)revcomp(f, t.m);
+  const uint32_t r = revcomp32(f, t.m);
   const uint32_t c = f < r ? f : r;
-  return ((uint64_t)(mm_order(c) & ~31u) << 32) | q;
+  return (mm_order(c) & ~SEL_POS) | q;
 }
 // Key of P given the window index u chosen by the scan.
 __device__ inline Key key_from_window(const TableView& t, uint64_t P, uint32_t u) {
@@ -216,30 +243,62 @@ __device__ inline uint32_t pick4(uint4 v, uint32_t i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// Linear probing inside the bucket [base, base + S), S > 0, continuing from the slot `a`
-// already loaded from base[idx]: counts of the four members of the group in slot order
-// (zeros if absent), as stored (u16, possibly COUNT_ESCAPE).  One 16-byte load per probe
-// step; *fetches counts the slots read.
-__device__ inline uint4 bucket_resolve(const Key& key, const Slot* base, uint64_t S, uint64_t idx,
-                                       uint4 a, uint32_t* fetches) {
-  for (uint64_t step = 0;;) {
+// Home slot of a key in a bucket of S slots (0 for an empty bucket).  Always even: the home
+// PAIR (home, home + 1) is one aligned 32-byte piece of a line, and the build guarantees that
+// every key sits inside its home pair (a bucket that cannot is doubled until it can).
+__device__ inline uint64_t home_slot(const TableView& t, const Key& key, uint64_t S) {
+  const uint64_t q = S >> t.cshift;
+  if (q) {
+    // class mode: S = q * NC, q even; the class owns q slots
+    return (uint64_t)key.cls * q + (__umulhi(key.hsub, (uint32_t)q) & ~1u);
+  }
+  // small bucket: floor(frac / 2^32 * S), order preserving
+  return (uint64_t)(__umulhi(key.frac, (uint32_t)S) & ~1u);
+}
+// slots of a bucket from its two directory words
+__device__ inline uint64_t bucket_slots(uint32_t lo, uint32_t hi) { return 2ull * (hi - lo); }
+
+__device__ inline uint4 slot_counts(uint4 a) {
+  return make_uint4(a.z & 0xFFFFu, a.z >> 16, a.w & 0xFFFFu, a.w >> 16);
+}
+
+// Counts of the four members of the group in slot order (zeros if absent), as stored (u16,
+// possibly COUNT_ESCAPE), given the two slots a0, a1 of the home pair at base[idx], already
+// loaded.  Normally (max_probe == 2) that is the whole search; a table whose build had to
+// give up on the pair bound keeps probing up to max_probe slots.  *fetches counts slots read.
+__device__ inline uint4 bucket_resolve2(const TableView& t, const Key& key, const Slot* base,
+                                        uint64_t S, uint64_t idx, uint4 a0, uint4 a1,
+                                        uint32_t* fetches) {
+  ++*fetches;
+  const uint64_t t0 = ((uint64_t)a0.y << 32) | a0.x;
+  if (t0 == key.tag) return slot_counts(a0);
+  if (t0 == EMPTY) return make_uint4(0, 0, 0, 0);
+  ++*fetches;
+  const uint64_t t1 = ((uint64_t)a1.y << 32) | a1.x;
+  if (t1 == key.tag) return slot_counts(a1);
+  if (t1 == EMPTY) return make_uint4(0, 0, 0, 0);
+  idx += 2;
+  for (uint32_t step = 2; step < t.max_probe && step < S; ++step) {
+    if (idx >= S) idx = 0;
+    const uint4 a = *reinterpret_cast<const uint4*>(base + idx);
     ++*fetches;
     const uint64_t tg = ((uint64_t)a.y << 32) | a.x;
-    if (tg == key.tag) return make_uint4(a.z & 0xFFFFu, a.z >> 16, a.w & 0xFFFFu, a.w >> 16);
-    if (tg == EMPTY || ++step >= S) break;
-    if (++idx == S) idx = 0;
-    a = *reinterpret_cast<const uint4*>(base + idx);
+    if (tg == key.tag) return slot_counts(a);
+    if (tg == EMPTY) break;
+    ++idx;
   }
   return make_uint4(0, 0, 0, 0);
 }
 
 __device__ inline uint4 bucket_lookup4(const TableView& t, const Key& key, uint32_t lo, uint32_t hi,
                                        uint32_t* fetches) {
-  const uint64_t S = (uint64_t)(hi - lo) * t.unit;
+  const uint64_t S = bucket_slots(lo, hi);
   if (S == 0) return make_uint4(0, 0, 0, 0);
-  const Slot* base = t.slots + (uint64_t)lo * t.unit;
-  const uint64_t idx = __umul64hi((uint64_t)key.frac << 32, S);
-  return bucket_resolve(key, base, S, idx, *reinterpret_cast<const uint4*>(base + idx), fetches);
+  const Slot* base = t.slots + 2ull * lo;
+  const uint64_t idx = home_slot(t, key, S);
+  const uint4 a0 = *reinterpret_cast<const uint4*>(base + idx);
+  const uint4 a1 = *reinterpret_cast<const uint4*>(base + idx + 1);
+  return bucket_resolve2(t, key, base, S, idx, a0, a1, fetches);
 }
 
 __device__ inline uint4 table_lookup4(const TableView& t, const Key& key, uint32_t* fetches) {

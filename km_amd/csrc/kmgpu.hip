@@ -90,6 +90,7 @@ struct kmjf {
   uint32_t* d_dir = nullptr;     // [n_buckets + 1] (+ padding) exclusive prefix of bucket sizes
   uint32_t n_buckets = 0;
   uint32_t unit = 2;
+  uint32_t max_probe = 2;
   OvfSlot* d_ovf = nullptr;
   uint64_t n_ovf = 0;
   uint64_t n_groups = 0;
@@ -108,12 +109,15 @@ static TableView view_of(const kmjf* h) {
   t.pmask = mask_bits(h->k - 1);
   t.n_buckets = h->n_buckets;
   t.unit = h->unit;
+  t.max_probe = h->max_probe;
   t.k = h->k;
   t.canonical = h->canonical;
   t.m = minimizer_len(h->k);
   t.w = h->k - t.m;
   t.mmask = (uint32_t)mask_bits(t.m);
   t.inv32 = (uint32_t)((1ull << 32) / ((uint64_t)2 * t.w * 256));
+  t.cshift = 1;
+  while ((1u << t.cshift) < 2u * (uint32_t)t.w) ++t.cshift;
   return t;
 }
 
@@ -214,8 +218,11 @@ static int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
-// Build: count entries per minimizer bucket -> exclusive scan (= the directory) -> allocate
-// `unit` slots per entry -> insert.  All on the device, from device-resident records.
+// Build, all on the device from device-resident records: count the entries of every minimizer
+// bucket -> capacities -> exclusive scan (= the directory) -> insert every key into its home
+// pair.  Buckets where some key found its pair taken are doubled and the table is rebuilt
+// (a handful of rounds); the result is a table in which every lookup reads exactly one
+// aligned 32-byte pair.
 extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_keys,
                                        const uint32_t* d_counts, uint64_t n, void* stream) {
   if (!h || (n && (!d_keys || !d_counts))) return fail(KM_E_ARG, "null argument");
@@ -224,37 +231,45 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   HIPCHK(hipSetDevice(device));
   // every record enters at most two groups
   const uint64_t max_entries = (h->canonical ? 2 : 1) * n;
-  if (max_entries >= (1ull << 32)) return fail(KM_E_CAPACITY, "more than 2^32 table entries");
-  // KM_TABLE_LOAD: load factor inside every bucket (HBM capacity is plentiful): unit = 1/load
+  if (max_entries >= (1ull << 31)) return fail(KM_E_CAPACITY, "more than 2^31 table entries");
+  // KM_TABLE_LOAD: initial load factor of every bucket (HBM capacity is plentiful): unit = 1/load
   uint32_t unit = 2;
   if (const char* lf = getenv("KM_TABLE_LOAD")) {
     double v = atof(lf);
     if (v >= 0.05 && v <= 0.5) unit = (uint32_t)(1.0 / v + 0.5);
   }
-  // KM_DIR_LOG2: log2 of the bucket count (default: about one bucket per 4 entries)
+  // KM_DIR_LOG2: log2 of the bucket count (default: about one bucket per 2 entries; a
+  // super-k-mer brings ~w entries of its own, so most buckets of real data are empty)
   uint32_t n_buckets = 1024;
-  while ((uint64_t)n_buckets * 4 < max_entries && n_buckets < (1u << 30)) n_buckets <<= 1;
+  while ((uint64_t)n_buckets * 2 < max_entries && n_buckets < (1u << 30)) n_buckets <<= 1;
   if (const char* dl = getenv("KM_DIR_LOG2")) { int v = atoi(dl); if (v >= 4 && v <= 30) n_buckets = 1u << v; }
   const uint32_t n_chunks = (uint32_t)(((uint64_t)n_buckets + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  const uint64_t dir_words = (uint64_t)n_chunks * SCAN_CHUNK;
   uint32_t* dir = nullptr;
+  uint32_t* caps = nullptr;
   uint32_t* sums = nullptr;
-  unsigned long long* d_meta = nullptr;   // [0] groups, [1] error flag (low 32 bits), [2] big counts
+  unsigned long long* d_meta = nullptr;   // [0] occupied slots, [1] error, [2] flagged buckets, [3] max probe distance,
+                                          // [4] big counts, [5] total capacity (pairs)
   Slot* slots = nullptr;
+  uint64_t slots_cap = 0;
   OvfSlot* ovf = nullptr;
   auto bail = [&](int code, const char* what, hipError_t e) {
     if (dir) (void)hipFree(dir);
+    if (caps) (void)hipFree(caps);
     if (sums) (void)hipFree(sums);
     if (d_meta) (void)hipFree(d_meta);
     if (slots) (void)hipFree(slots);
     if (ovf) (void)hipFree(ovf);
     return fail(code, "%s: %s", what, hipGetErrorString(e));
   };
-  hipError_t e = hipMalloc((void**)&dir, (uint64_t)n_chunks * SCAN_CHUNK * 4);
+  hipError_t e = hipMalloc((void**)&dir, dir_words * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&caps, dir_words * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&sums, (uint64_t)n_chunks * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_meta, 32);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_meta, 64);
   if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
-  (void)hipMemsetAsync(dir, 0, (uint64_t)n_chunks * SCAN_CHUNK * 4, st);
-  (void)hipMemsetAsync(d_meta, 0, 32, st);
+  (void)hipMemsetAsync(dir, 0, dir_words * 4, st);
+  (void)hipMemsetAsync(caps, 0, dir_words * 4, st);
+  (void)hipMemsetAsync(d_meta, 0, 64, st);
 
   kmjf shape;               // a view with the geometry only, for the build kernels
   shape.k = h->k; shape.canonical = h->canonical;
@@ -262,46 +277,84 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   TableView tv = view_of(&shape);
   shape.d_dir = nullptr;    // not owned
 
-  unsigned long long n_big = 0;
-  uint32_t entries = 0;
   if (n) {
-    hipLaunchKernelGGL(k_count_big, dim3(grid_for(n, 256)), dim3(256), 0, st, d_counts, n, d_meta + 2);
-    hipLaunchKernelGGL(k_dir_count, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, d_keys, d_counts, n, dir);
+    hipLaunchKernelGGL(k_count_big, dim3(grid_for(n, 256)), dim3(256), 0, st, d_counts, n, d_meta + 4);
+    hipLaunchKernelGGL(k_dir_count, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, d_keys, d_counts, n, caps);
   }
-  hipLaunchKernelGGL(k_scan_reduce, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, dir, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, n_chunks);
-  hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, dir, sums);
-  e = hipMemcpyAsync(&n_big, d_meta + 2, 8, hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(&entries, dir + n_buckets, 4, hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return bail(KM_E_HIP, "count pass failed", e);
-
-  const uint64_t n_slots = std::max<uint64_t>(64, (uint64_t)entries * unit);
-  e = hipMalloc((void**)&slots, n_slots * sizeof(Slot));
-  if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
+  hipLaunchKernelGGL(k_dir_capacity, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
+                     (uint64_t)n_buckets, unit, tv.cshift);
+  const int MAX_ROUNDS = 12;
+  const uint64_t GROW_LIMIT = 4096;     // slots: a heavier bucket probes linearly instead of doubling
+  unsigned long long meta[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t n_slots = 0;
+  uint32_t max_probe = 2;
+  int rounds = 0;
+  for (;; ++rounds) {
+    const uint64_t grow_limit = rounds < MAX_ROUNDS ? GROW_LIMIT : 0;
+    (void)hipMemsetAsync(d_meta, 0, 32, st);          // [0..3]
+    (void)hipMemsetAsync(d_meta + 5, 0, 8, st);
+    hipLaunchKernelGGL(k_dir_copy, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps, dir,
+                       (uint64_t)n_buckets, d_meta + 5);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, dir, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, n_chunks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, dir, sums);
+    e = hipMemcpyAsync(meta, d_meta, 48, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bail(KM_E_HIP, "directory pass failed", e);
+    if (meta[5] >= (1ull << 32))
+      return bail(KM_E_CAPACITY, "table needs more than 2^33 slots (32-bit directory)", hipSuccess);
+    n_slots = std::max<uint64_t>(64, 2ull * meta[5]);
+    if (n_slots > slots_cap) {
+      if (slots) (void)hipFree(slots);
+      slots = nullptr;
+      slots_cap = n_slots + n_slots / 4;              // head room for the following rounds
+      e = hipMalloc((void**)&slots, slots_cap * sizeof(Slot));
+      if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
+    }
+    hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
+    if (n)
+      hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, slots, d_keys,
+                         d_counts, n, caps, grow_limit, d_meta);
+    e = hipMemcpyAsync(meta, d_meta, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bail(KM_E_HIP, "table build failed", e);
+    if (meta[1] & 0xFFFFFFFFull) return bail(KM_E_HIP, "table build overflowed", hipSuccess);
+    max_probe = std::max<uint32_t>(2, (uint32_t)meta[3] + 1);
+    if (getenv("KM_BUILD_VERBOSE"))
+      fprintf(stderr, "libkmgpu: build round %d: %llu slots, %llu buckets to grow, max distance %llu\n", rounds,
+              (unsigned long long)n_slots, meta[2], meta[3]);
+    if (!grow_limit) break;
+    if (meta[2] == 0) break;
+    hipLaunchKernelGGL(k_dir_grow, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
+                       (uint64_t)n_buckets, tv.cshift);
+  }
+  if (getenv("KM_BUILD_VERBOSE"))
+    fprintf(stderr, "libkmgpu: table built in %d round(s): %llu slots for %llu groups, max_probe %u\n",
+            rounds + 1, (unsigned long long)n_slots, meta[0], max_probe);
   // side table for the (rare) counts that do not fit 16 bits
+  const uint64_t n_big = meta[4];
   const uint64_t n_ovf = n_big ? (n_big * 2 + 64) : 0;
   if (n_ovf) {
     e = hipMalloc((void**)&ovf, n_ovf * sizeof(OvfSlot));
     if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
     (void)hipMemsetAsync(ovf, 0, n_ovf * sizeof(OvfSlot), st);
+    (void)hipMemsetAsync(d_meta + 1, 0, 8, st);
+    hipLaunchKernelGGL(k_ovf_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, d_keys, d_counts, n, h->k,
+                       h->canonical, ovf, n_ovf, reinterpret_cast<unsigned int*>(d_meta + 1));
+    unsigned long long err = 0;
+    e = hipMemcpyAsync(&err, d_meta + 1, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bail(KM_E_HIP, "side table build failed", e);
+    if (err & 0xFFFFFFFFull) return bail(KM_E_HIP, "side table overflowed", hipSuccess);
   }
-  hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
-  if (n)
-    hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, slots,
-                       d_keys, d_counts, n, ovf, n_ovf, d_meta,
-                       reinterpret_cast<unsigned int*>(d_meta + 1));
-  unsigned long long meta[2] = {0, 0};
-  e = hipMemcpyAsync(meta, d_meta, 16, hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return bail(KM_E_HIP, "table build failed", e);
-  if (meta[1] & 0xFFFFFFFFull) return bail(KM_E_HIP, "table build overflowed", hipSuccess);
+  (void)hipFree(caps);
   (void)hipFree(sums);
   (void)hipFree(d_meta);
   h->d_slots = slots;
   h->d_dir = dir;
   h->n_buckets = n_buckets;
   h->unit = unit;
+  h->max_probe = max_probe;
   h->d_ovf = ovf;
   h->n_ovf = n_ovf;
   h->n_slots = n_slots;
@@ -489,6 +542,7 @@ struct km_batch {
   uint64_t path_pool = 0, run_pool = 0;
   // big tier
   DevBuf<unsigned char> d_frames;     // fast-tier DFS stack frames, one slice per target
+  DevBuf<unsigned long long> d_stamps; // diagnostics: k_seed time stamps (KM_SEED_STAMPS)
   DevBuf<float> d_tref;               // shared reference-chain distances
   DevBuf<uint32_t> d_big_ids;
   DevBuf<unsigned char> d_big_ws;
@@ -602,7 +656,7 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
-  b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release();
+  b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release(); b->d_stamps.release();
   for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   delete b;
   return KM_OK;
@@ -801,6 +855,31 @@ static int launch_graph_fast(km_batch* b, hipStream_t st) {
   return KM_OK;
 }
 
+// k_seed: KM_SEED_NS (1, 2 or 4) item records per wave group, KM_SEED_BLOCK (64, 128 or 256)
+// threads per block — the waves of a block do not cooperate
+static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
+  static const int ns = [] {
+    const char* e = getenv("KM_SEED_NS");
+    const int v = e ? atoi(e) : SEED_NS;
+    return (v == 1 || v == 2 || v == 4) ? v : SEED_NS;
+  }();
+  static const int bs = [] {
+    const char* e = getenv("KM_SEED_BLOCK");
+    const int v = e ? atoi(e) : (int)SEED_BLOCK;
+    return (v == 64 || v == 128 || v == 256) ? v : (int)SEED_BLOCK;
+  }();
+  const int wpb = bs / 64;
+  if (wa.stamps) {          // diagnostics build of the kernel (KM_SEED_STAMPS)
+    hipLaunchKernelGGL((k_seed<1, true>), dim3((n_items * 4 + wpb - 1) / wpb), dim3(bs), 0, st, wa);
+    return;
+  }
+  const uint32_t units = ((n_items + ns - 1) / ns) * 4;
+  const dim3 grid((units + wpb - 1) / wpb), block(bs);
+  if (ns == 1) hipLaunchKernelGGL((k_seed<1, false>), grid, block, 0, st, wa);
+  else if (ns == 2) hipLaunchKernelGGL((k_seed<2, false>), grid, block, 0, st, wa);
+  else hipLaunchKernelGGL((k_seed<4, false>), grid, block, 0, st, wa);
+}
+
 extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   if (!b) return fail(KM_E_ARG, "null argument");
   if (!b->n_targets) { b->ran_walk = true; b->ran_graph = (stages & KM_STAGE_GRAPH) != 0; return KM_OK; }
@@ -834,6 +913,12 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     if (rc != KM_OK) return rc;
   }
   wa.f_ws = b->d_frames.p;
+  wa.stamps = nullptr;
+  if (getenv("KM_SEED_STAMPS")) {
+    int rc = b->d_stamps.alloc(16ull * (SEED_BLOCK / 64) * (b->n_items + 4));
+    if (rc != KM_OK) return rc;
+    wa.stamps = b->d_stamps.p;
+  }
   b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
   GraphArgs& ga = b->ga;
   fill_graph_args(b, ga);
@@ -859,7 +944,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
     if (!capturing) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
-      hipLaunchKernelGGL(k_seed<SEED_NS>, dim3((b->n_items + SEED_NS - 1) / SEED_NS), dim3(SEED_BLOCK), 0, st, wa);
+      launch_seed(b->n_items, st, wa);
     if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
     if (b->fast_ok) {
       // unflagged targets are final after k_seed: their pure-chain check runs on the side
@@ -1131,6 +1216,18 @@ extern "C" int km_batch_sync(km_batch_t* b) {
     }
   }
   b->synced = true;
+  return KM_OK;
+}
+
+extern "C" int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_words, uint64_t* n_words) {
+  if (!b || !n_words) return fail(KM_E_ARG, "null argument");
+  int rc = km_batch_sync(b);
+  if (rc != KM_OK) return rc;
+  const uint64_t n = b->d_stamps.p ? 16ull * (SEED_BLOCK / 64) * b->n_items : 0;
+  *n_words = n;
+  if (!dst || !n) return KM_OK;
+  if (cap_words < n) return fail(KM_E_CAPACITY, "stamp buffer too small");
+  HIPCHK(hipMemcpy(dst, b->d_stamps.p, n * 8, hipMemcpyDeviceToHost));
   return KM_OK;
 }
 

@@ -50,6 +50,47 @@ __global__ void k_dir_count(TableView t, const uint64_t* keys, const uint32_t* c
   }
 }
 
+// Capacity rules (slots; stored in units of 2 slots).  Small buckets: `unit` slots per entry,
+// fewer than NC slots.  Class mode: a multiple of 2*NC slots (q even), at least 2*NC.
+__device__ inline uint64_t shape_capacity(uint64_t cap, uint64_t NC) {
+  cap += cap & 1;
+  if (cap >= NC) cap = (cap + 2 * NC - 1) / (2 * NC) * (2 * NC);
+  return cap;
+}
+constexpr uint32_t CAP_GROW = 0x80000000u;   // flag in caps[]: some key did not fit its home pair
+
+// Entry count -> initial capacity, in place.
+__global__ void k_dir_capacity(uint32_t* caps, uint64_t n, uint32_t unit, uint32_t cshift) {
+  const uint64_t NC = 1ull << cshift;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    caps[i] = (uint32_t)(shape_capacity((uint64_t)caps[i] * unit, NC) >> 1);
+}
+
+// Double every flagged bucket (and clear its flag).
+__global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift) {
+  const uint64_t NC = 1ull << cshift;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = caps[i];
+    if (c & CAP_GROW) caps[i] = (uint32_t)(shape_capacity(4ull * (c & ~CAP_GROW), NC) >> 1);
+  }
+}
+
+// caps -> dir (to be scanned in place) and the total, which must fit the 32-bit directory.
+__global__ void k_dir_copy(const uint32_t* caps, uint32_t* dir, uint64_t n,
+                           unsigned long long* total_pairs) {
+  unsigned long long local = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = caps[i] & ~CAP_GROW;
+    dir[i] = c;
+    local += c;
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(total_pairs, local);
+}
+
 // Exclusive prefix sum of the bucket counts, in place (three passes over chunks of
 // SCAN_CHUNK words; the array is zero-padded to a whole number of chunks).
 constexpr int SCAN_THREADS = 256;
@@ -126,12 +167,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* data, con
   }
 }
 
-// Pass 2: one record per thread, entered under the group of each orientation, by linear
-// probing from its order-preserving home inside its bucket.  err[0] != 0 on return means a
-// bucket was too small (cannot happen: buckets are sized from the same entry counts).
+// Exact values of the counts that do not fit 16 bits, keyed by the k-mer as stored.
+__global__ void k_ovf_insert(const uint64_t* keys, const uint32_t* counts, uint64_t n, int k,
+                             int canonical, OvfSlot* ovf, uint64_t n_ovf, unsigned int* err) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t K = keys[i];
+    const uint32_t v = counts[i];
+    if (v < COUNT_ESCAPE) continue;
+    uint64_t R;
+    if (record_orientations(K, k, canonical, &R) == 0) continue;
+    bool placed = false;
+    uint64_t oi = n_ovf ? slot_index(K, n_ovf) : 0;
+    for (uint64_t step = 0; step < n_ovf; ++step) {
+      if (atomicCAS(&ovf[oi].count, 0u, v) == 0u) { ovf[oi].kmer = K; placed = true; break; }
+      if (++oi == n_ovf) oi = 0;
+    }
+    if (!placed) atomicExch(err, 1u);
+  }
+}
+
+// Insert pass: one record per thread, entered under the group of each orientation into the
+// home pair of its bucket.  A key whose home pair is taken flags its bucket in caps[]
+// (meta[2] counts flagged buckets) — the host doubles those buckets and rebuilds — unless the
+// bucket already holds grow_limit slots or more: such a heavy bucket (a minimizer shared by
+// very many k-mers) keeps probing linearly instead, and meta[3] records the largest probe
+// distance used.  meta[0] counts occupied slots, meta[1] != 0 reports a full bucket.
 __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
-                               const uint32_t* counts, uint64_t n, OvfSlot* ovf, uint64_t n_ovf,
-                               unsigned long long* n_groups, unsigned int* err) {
+                               const uint32_t* counts, uint64_t n, uint32_t* caps,
+                               uint64_t grow_limit, unsigned long long* meta) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t K = keys[i];
@@ -139,39 +203,36 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
     if (v == 0) continue;
     uint64_t R;
     const int n_or = record_orientations(K, t.k, t.canonical, &R);
-    if (n_or == 0) continue;
-    if (v >= COUNT_ESCAPE) {
-      // exact value to the side table (keyed by the k-mer as stored)
-      bool placed = false;
-      uint64_t oi = n_ovf ? slot_index(K, n_ovf) : 0;
-      for (uint64_t step = 0; step < n_ovf; ++step) {
-        if (atomicCAS(&ovf[oi].count, 0u, v) == 0u) { ovf[oi].kmer = K; placed = true; break; }
-        if (++oi == n_ovf) oi = 0;
-      }
-      if (!placed) atomicExch(err, 1u);
-    }
     for (int o = 0; o < n_or; ++o) {
       const uint64_t O = o ? R : K;
       const Key g = make_key(t, O >> 2);
       uint32_t s = (uint32_t)(O & 3);
       if (g.flip) s = 3 - s;
       const uint32_t lo = t.dir[g.bucket], hi = t.dir[g.bucket + 1];
-      const uint64_t S = (uint64_t)(hi - lo) * t.unit;
-      Slot* base = slots + (uint64_t)lo * t.unit;
-      uint64_t idx = S ? __umul64hi((uint64_t)g.frac << 32, S) : 0;
+      const uint64_t S = bucket_slots(lo, hi);
+      Slot* base = slots + 2ull * lo;
+      uint64_t idx = home_slot(t, g, S);
       bool done = false;
       for (uint64_t step = 0; step < S; ++step) {
+        if (step == 2 && S < grow_limit) break;         // the pair is taken: grow this bucket
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&base[idx].tag),
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
-        if (old == EMPTY) atomicAdd(n_groups, 1ull);
+        if (old == EMPTY) atomicAdd(&meta[0], 1ull);
         if (old == EMPTY || old == g.tag) {
           base[idx].c[s] = (uint16_t)(v >= COUNT_ESCAPE ? COUNT_ESCAPE : v);
+          if (step >= 2) atomicMax(&meta[3], (unsigned long long)step);
           done = true;
           break;
         }
         if (++idx == S) idx = 0;
       }
-      if (!done) atomicExch(err, 1u);
+      if (!done) {
+        if (S < grow_limit) {
+          if (!(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW)) atomicAdd(&meta[2], 1ull);
+        } else {
+          atomicExch(reinterpret_cast<unsigned int*>(&meta[1]), 1u);
+        }
+      }
     }
   }
 }

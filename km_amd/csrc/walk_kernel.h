@@ -102,6 +102,7 @@ struct WalkArgs {
   uint64_t g_stride;    // BIG only: bytes per block
   unsigned char* f_ws;  // fast tier: global scratch for the DFS stack frames (per block)
   uint64_t f_stride;
+  unsigned long long* stamps;  // diagnostics (KM_SEED_STAMPS): 16 words per k_seed wave, else null
 };
 
 // Per-target k_dfs state.  BIG tier: everything in one global block.  Fast tier: node
@@ -238,98 +239,168 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
 
 // ---------------------------------------------------------------------------- k_seed
 constexpr int SEED_NS = 2;   // item records per k_seed block
+// Diagnostic time stamps of k_seed (only when WalkArgs::stamps is set): every stamp first
+// drains the outstanding loads, so the difference of two stamps is the full latency of the
+// stage between them.
+#define KM_SEED_STAMP(n)                                                                  \
+  do {                                                                                    \
+    if constexpr (STAMPS) {                                                               \
+      unsigned long long t_;                                                              \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" \
+                   : "=s"(t_)::"memory");                                                 \
+      ts[n] = t_;                                                                         \
+    }                                                                                     \
+  } while (0)
+
+// Sliding-window minimum over w consecutive selection keys, for the 64 + w positions a wave
+// needs: row[q] holds the key of base position q (q < 64 + w valid, the rest don't-care).
+// Log-step doubling between two ping-pong rows; KK = largest power of two <= w.
+constexpr uint32_t SCAN_ROW = 160;
+template <uint32_t KK>
+__device__ inline void scan_min(uint32_t (*buf)[SCAN_ROW], uint32_t lane, uint32_t W,
+                                uint32_t* m_child, uint32_t* m_first) {
+  uint32_t src = 0;
+#pragma unroll
+  for (uint32_t d = 1; d < KK; d <<= 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t a0 = buf[src][lane], a1 = buf[src][lane + d];
+    const uint32_t e0 = buf[src][64 + lane], e1 = buf[src][64 + lane + d];
+    buf[src ^ 1][lane] = a0 < a1 ? a0 : a1;
+    buf[src ^ 1][64 + lane] = e0 < e1 ? e0 : e1;
+    src ^= 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const uint32_t m0 = buf[src][lane + 1], m1 = buf[src][lane + 1 + W - KK];
+  const uint32_t f0 = buf[src][0], f1 = buf[src][W - KK];
+  *m_child = m0 < m1 ? m0 : m1;      // (k-1)-mer starting at base q = lane + 1
+  *m_first = f0 < f1 ? f0 : f1;      // (k-1)-mer starting at base 0
+}
+
 // One lane per target k-mer ("seed"): its count, its get_child and the trivial / flagged
 // decision.  Every block works on NS item records at once and keeps the NS independent
 // chains  bases -> minimizer -> directory word -> slot  in flight together: the kernel is
 // bound by the latency of that chain, not by HBM bandwidth.
-template <int NS>
+template <int NS, bool STAMPS>
 __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   static_assert(SEED_BLOCK == 256, "the item record holds 12 words = 256 seeds + k - 1 + 1 bases");
-  // per wave: two ping-pong rows of 96 sliding-window keys (64 own positions + up to w beyond)
-  __shared__ uint64_t win[SEED_BLOCK / 64][2][96];
+  // per wave: two ping-pong rows of sliding-window keys (64 own positions + up to w beyond)
+  __shared__ uint32_t win[SEED_BLOCK / 64][2][SCAN_ROW];
   const TableView tab = a.tab;
   const int k = tab.k;
   const uint32_t lane = threadIdx.x & 63u;
-  uint64_t (*buf)[96] = win[threadIdx.x >> 6];
+  uint32_t (*buf)[SCAN_ROW] = win[threadIdx.x >> 6];
   const uint32_t W = (uint32_t)tab.w;
   const uint32_t K = 1u << (31 - __clz((int)W));           // largest power of two <= w
+  // Waves do not cooperate (any block size that is a multiple of 64 works).  Work unit gw =
+  // 64 seeds: four consecutive units share an item record; tid = this lane's seed within the
+  // record.  (A persistent grid-stride version was measured: the loop-carried uniforms cost
+  // 25 more VGPRs and it was 10 % slower.)
+  const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  {
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long real0 = 0;
+  uint32_t probes_first = 0;                               // diagnostics: slots read by this lane's lookup
+  if constexpr (STAMPS) real0 = __builtin_amdgcn_s_memrealtime();
+  KM_SEED_STAMP(0);
+  const uint32_t tid = ((gw & 3u) << 6) | lane;
 
   const uint64_t* rec[NS];
   bool live[NS];
   uint32_t tgt[NS], idx0[NS], n_ref[NS];
+  uint64_t nb[NS], fwo[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const uint32_t item = blockIdx.x * NS + s;
+    const uint32_t item = (gw >> 2) * NS + s;
     live[s] = item < a.n_items;
     rec[s] = a.items + 16ull * (live[s] ? item : 0u);
     const uint64_t h0 = rec[s][0], h1 = rec[s][1];
+    nb[s] = rec[s][2];
+    fwo[s] = rec[s][3];
     live[s] = live[s] && (uint32_t)(h1 >> 32) != 0u;       // else: target not walkable (status != OK)
     tgt[s] = (uint32_t)h0;
-    idx0[s] = (uint32_t)(h0 >> 32) + threadIdx.x;          // the first seed of an item is a multiple of 256
+    idx0[s] = (uint32_t)(h0 >> 32) + tid;                  // the first seed of an item is a multiple of 256
     n_ref[s] = (uint32_t)h1;
   }
+  KM_SEED_STAMP(1);
   // 64 bits of the target starting at item-relative base q
   auto bits_at = [&](const uint64_t* r, uint32_t q) -> uint64_t {
     const uint32_t w = q >> 5, sh = (q & 31) * 2;
     const uint64_t hi = r[4 + w], lo = r[5 + w];
-    return sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+    return (hi << sh) | ((lo >> 1) >> (63 - sh));
   };
   uint64_t x[NS], xe[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    x[s] = bits_at(rec[s], threadIdx.x);
-    xe[s] = lane < W ? bits_at(rec[s], (threadIdx.x & ~63u) + 64 + lane) : 0ull;
+    x[s] = bits_at(rec[s], tid);
+    xe[s] = bits_at(rec[s], tid + 64);             // used by the lanes < w only
   }
 
+  KM_SEED_STAMP(2);
   // ---- minimizers of all (k-1)-mers of this wave's 64 seeds in one sliding-window scan:
-  // lane l owns the m-mer at wave-relative base q = l, lanes < w also q = 64 + l; the
-  // minimizer of the (k-1)-mer starting at base q is min over q .. q+w-1 (log-step doubling).
+  // lane l owns the m-mer at wave-relative base q = l and (lanes < w) q = 64 + l; the
+  // minimizer of the (k-1)-mer starting at base q is the minimum over q .. q+w-1.
   uint32_t u_child[NS], u_first[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     buf[0][lane] = mmer_scan_key(tab, x[s], lane);
-    if (lane < 32) buf[0][64 + lane] = lane < W ? mmer_scan_key(tab, xe[s], 64 + lane) : ~0ull;
-    uint32_t src = 0;
-    for (uint32_t d = 1; d < K; d <<= 1) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint64_t a0 = buf[src][lane], a1 = buf[src][lane + d];
-      buf[src ^ 1][lane] = a0 < a1 ? a0 : a1;
-      if (lane < 32) {
-        const uint32_t q = 64 + lane;
-        const uint64_t b0 = buf[src][q], b1 = q + d < 96 ? buf[src][q + d] : ~0ull;
-        buf[src ^ 1][q] = b0 < b1 ? b0 : b1;
-      }
-      src ^= 1;
+    buf[0][64 + lane] = mmer_scan_key(tab, xe[s], 64 + lane);
+    uint32_t mc, mf;
+    switch (K) {
+      case 16: scan_min<16>(buf, lane, W, &mc, &mf); break;
+      case 8: scan_min<8>(buf, lane, W, &mc, &mf); break;
+      case 4: scan_min<4>(buf, lane, W, &mc, &mf); break;
+      case 2: scan_min<2>(buf, lane, W, &mc, &mf); break;
+      default: scan_min<1>(buf, lane, W, &mc, &mf); break;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint64_t m0 = buf[src][lane + 1], m1 = buf[src][lane + 1 + W - K];
-    u_child[s] = (uint32_t)(m0 < m1 ? m0 : m1) - (lane + 1);  // window of X[1:] (starts at base q = l+1)
-    const uint64_t f0 = buf[src][0], f1 = buf[src][W - K];
-    u_first[s] = (uint32_t)(f0 < f1 ? f0 : f1);                // window of X[:-1] of lane 0 (base 0)
+    u_child[s] = (mc & SEL_POS) - (lane + 1);
+    u_first[s] = mf & SEL_POS;
   }
 
-  // ---- keys, directory words, first probes: all NS loads of a stage are issued together
-  uint64_t X[NS], S[NS], pos[NS];
-  Key g[NS];
-  DirPair dw[NS];
+  KM_SEED_STAMP(3);
+  // ---- keys, directory words, first two probe slots: all loads of a stage are issued
+  // together.  The wave holding seed 0 of a target also needs query(ref[0]) (its (k-1)-mer
+  // prefix starts at base 0); that lookup rides along as one more independent chain.
+  uint64_t X[NS], S[NS], pos[NS], Sq[NS], posq[NS];
+  Key g[NS], gq[NS];
+  DirPair dw[NS], dq[NS];
   const Slot* base[NS];
-  uint4 first[NS];
+  const Slot* baseq[NS];
+  uint4 first[NS], second[NS], firstq[NS], secondq[NS];
+  bool head[NS];                                           // wave-uniform: this wave holds seed 0
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     X[s] = x[s] >> (64 - 2 * k);
-    g[s] = key_from_window(tab, X[s] & tab.pmask, (a.dbg & 0x10u) ? 0u : u_child[s]);
+    g[s] = key_from_window(tab, X[s] & tab.pmask, u_child[s]);
     dw[s] = *reinterpret_cast<const DirPair*>(tab.dir + g[s].bucket);
+    head[s] = idx0[s] == lane;
+    if (head[s]) {
+      gq[s] = key_from_window(tab, X[s] >> 2, u_first[s]);
+      dq[s] = *reinterpret_cast<const DirPair*>(tab.dir + gq[s].bucket);
+    }
   }
+  KM_SEED_STAMP(4);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    S[s] = (uint64_t)(dw[s].hi - dw[s].lo) * tab.unit;
-    base[s] = tab.slots + (uint64_t)dw[s].lo * tab.unit;
-    pos[s] = S[s] ? __umul64hi((uint64_t)g[s].frac << 32, S[s]) : 0;
-    first[s] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-    if (S[s]) first[s] = *reinterpret_cast<const uint4*>(base[s] + pos[s]);
+    S[s] = bucket_slots(dw[s].lo, dw[s].hi);
+    base[s] = tab.slots + 2ull * dw[s].lo;
+    pos[s] = home_slot(tab, g[s], S[s]);                   // 0 for an empty bucket
+    // the home pair, loaded unconditionally (an empty bucket reads some valid slots and
+    // ignores them): keeps the loads independent of each other
+    const Slot* b0 = S[s] ? base[s] : tab.slots;
+    first[s] = *reinterpret_cast<const uint4*>(b0 + pos[s]);
+    second[s] = *reinterpret_cast<const uint4*>(b0 + pos[s] + 1);
+    if (head[s]) {
+      Sq[s] = bucket_slots(dq[s].lo, dq[s].hi);
+      baseq[s] = tab.slots + 2ull * dq[s].lo;
+      posq[s] = home_slot(tab, gq[s], Sq[s]);
+      const Slot* bq = Sq[s] ? baseq[s] : tab.slots;
+      firstq[s] = *reinterpret_cast<const uint4*>(bq + posq[s]);
+      secondq[s] = *reinterpret_cast<const uint4*>(bq + posq[s] + 1);
+    }
   }
 
+  KM_SEED_STAMP(5);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     if (!live[s]) continue;                                // block-uniform
@@ -338,25 +409,37 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
     bool valid = false, triv = false, triv_child = false;
     if (i < n_ref[s]) {
       valid = true;
-      const uint64_t nb = rec[s][2];
-      a.node_kmer[nb + i] = X[s];
       uint4 c4 = make_uint4(0, 0, 0, 0);
-      if (S[s]) c4 = bucket_resolve(g[s], base[s], S[s], pos[s], first[s], &fetch_l);
+      if (S[s]) c4 = bucket_resolve2(tab, g[s], base[s], S[s], pos[s], first[s], second[s], &fetch_l);
       c4 = finish_children(tab, X[s], g[s].flip, c4);
+      if (s == 0) KM_SEED_STAMP(6);
+      if constexpr (STAMPS) { if (s == 0) probes_first = fetch_l; }
+      a.node_kmer[nb[s] + i] = X[s];
       uint32_t nextb = 4;
       if (i + 1 < n_ref[s]) {
-        const uint32_t p = threadIdx.x + (uint32_t)k;     // last base of ref[i+1], item-relative
-        nextb = (uint32_t)(rec[s][4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
-        a.node_cnt[nb + i + 1] = pick4(c4, nextb);
+        // last base of ref[i+1] = base k of this lane's 32-base window (k <= 31), else reloaded
+        if (k < 32) {
+          nextb = (uint32_t)(x[s] >> (62 - 2 * k)) & 3u;
+        } else {
+          const uint32_t p = tid + (uint32_t)k;
+          nextb = (uint32_t)(rec[s][4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+        }
+        a.node_cnt[nb[s] + i + 1] = pick4(c4, nextb);
       }
-      if (i == 0)
-        a.node_cnt[nb] = query_one_keyed(tab, X[s], key_from_window(tab, X[s] >> 2, u_first[s]), &fetch_l);
+      if (i == 0) {                                        // node_data[ref[0]] = jf.query(ref[0])
+        uint4 cq = make_uint4(0, 0, 0, 0);
+        if (Sq[s]) cq = bucket_resolve2(tab, gq[s], baseq[s], Sq[s], posq[s], firstq[s], secondq[s], &fetch_l);
+        const uint32_t sb = (uint32_t)(X[s] & 3);
+        uint32_t v = pick4(cq, gq[s].flip ? 3 - sb : sb);
+        if (v == COUNT_ESCAPE) v = overflow_count(tab, X[s]);
+        a.node_cnt[nb[s]] = v;
+      }
       if (a.max_stack > 0) {
         const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
         triv = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
         triv_child = triv && mask != 0;
         if (!triv) {
-          atomicOr(&a.flagbits[rec[s][3] + (i >> 5)], 1u << (i & 31));
+          atomicOr(&a.flagbits[fwo[s] + (i >> 5)], 1u << (i & 31));
           if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
         }
       }
@@ -371,6 +454,25 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
       atomicAdd(&a.probes[t], probes_w);
       atomicAdd(&a.fetches[t], (unsigned long long)fetch_l);
     }
+  }
+  if constexpr (STAMPS) {
+    KM_SEED_STAMP(7);
+    const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t pmax = probes_first, psum = probes_first;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+      const uint32_t v = __shfl_xor(pmax, o2);
+      pmax = v > pmax ? v : pmax;
+      psum += __shfl_xor(psum, o2);
+    }
+    if (lane == 0) {
+      unsigned long long* o = a.stamps + 16ull * gw;
+      for (int q = 0; q < 8; ++q) o[q] = ts[q];
+      o[8] = real0; o[9] = real1;
+      o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave, SIMD, CU, SH, SE
+      o[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+      o[12] = pmax; o[13] = psum;
+    }
+  }
   }
 }
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
-    "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_strerror", "km_last_error",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_batch_debug_stamps", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
 
@@ -99,6 +99,7 @@ def load():
         "km_batch_sizes": [vp, C.POINTER(BatchSizes)],
         "km_batch_fetch": [vp, C.POINTER(BatchOut)],
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
+        "km_batch_debug_stamps": [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)],
         "km_device_count": [C.POINTER(i32)],
         "km_stream_create": [i32, C.POINTER(vp)],
         "km_stream_destroy": [vp],
@@ -298,6 +299,15 @@ class Batch:
         ms = (C.c_float * 4)()
         check(self._lib.km_batch_timings(self._b, ms))
         return float(ms[0]), float(ms[1]), float(ms[2]), float(ms[3])
+
+    def debug_stamps(self):
+        """k_seed time stamps (KM_SEED_STAMPS diagnostics): uint64 array [n_waves, 16]."""
+        n = C.c_uint64(0)
+        check(self._lib.km_batch_debug_stamps(self._b, None, 0, C.byref(n)))
+        out = np.zeros(int(n.value), dtype=np.uint64)
+        if n.value:
+            check(self._lib.km_batch_debug_stamps(self._b, out.ctypes.data_as(C.c_void_p), n, C.byref(n)))
+        return out.reshape(-1, 16)
 
     def sizes(self):
         s = BatchSizes()
