@@ -149,9 +149,10 @@ __host__ __device__ inline uint32_t mm_bucket(uint32_t c) {
   return h;
 }
 
-// Window j of P (bases j .. j+m-1): selection key (25 bits of order hash above 7 bits of
+// Window j of P (bases j .. j+m-1): selection key (23 bits of order hash above 9 bits of
 // position, so the smallest key is the leftmost smallest minimizer), canonical m-mer, strand.
-constexpr uint32_t SEL_POS = 127u;
+// 9 bits: k_seed tags the keys of a whole item record (256 + w positions) this way.
+constexpr uint32_t SEL_POS = 511u;
 __host__ __device__ inline uint32_t window_key(const TableView& t, uint64_t P, uint64_t R, int j,
                                                uint32_t* canon, uint32_t* strand) {
   const uint32_t f = (uint32_t)(P >> (2 * (t.w - 1 - j))) & t.mmask;
@@ -217,7 +218,7 @@ __device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
   return key;
 }
 
-// Sliding-window form used by k_seed (one lane per base position q < 128 of a sequence): the
+// Sliding-window form used by k_seed (one lane per base position q < 512 of a sequence): the
 // selection key of the m-mer whose 64 leading bits are `bits`, tagged with its position.
 // min over q .. q+w-1 of these keys picks the same window as make_key (smallest order hash,
 // leftmost on ties).
@@ -381,16 +382,14 @@ __device__ inline uint32_t query_one(const TableView& t, uint64_t X, uint32_t* f
 // evaluated as Python does (float64 product, exact int/float comparison):
 // km/utils/Jellyfish.py:69-72.  Returns a 4-bit mask, bit c = child base c.
 __device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) {
-  uint64_t sum = (uint64_t)c.x + c.y + c.z + c.w;
-  double t = (double)sum * ratio;
-  double nc = (double)n_cutoff;
-  double thr = (nc > t) ? nc : t;          // Python max(t, nc)
-  uint32_t m = 0;
-  m |= ((double)c.x >= thr) ? 1u : 0u;
-  m |= ((double)c.y >= thr) ? 2u : 0u;
-  m |= ((double)c.z >= thr) ? 4u : 0u;
-  m |= ((double)c.w >= thr) ? 8u : 0u;
-  return m;
+  const double t = (double)((uint64_t)c.x + c.y + c.z + c.w) * ratio;
+  const double nc = (double)n_cutoff;
+  const double thr = (nc > t) ? nc : t;     // Python max(t, nc)
+  // an integer count is >= thr  <=>  it is >= ceil(thr): four integer compares
+  const double ct = ceil(thr);
+  if (!(ct < 4294967296.0)) return 0u;      // above every 32-bit count (or NaN): none kept
+  const uint32_t T = ct <= 0.0 ? 0u : (uint32_t)ct;
+  return (c.x >= T ? 1u : 0u) | (c.y >= T ? 2u : 0u) | (c.z >= T ? 4u : 0u) | (c.w >= T ? 8u : 0u);
 }
 
 }  // namespace kmd

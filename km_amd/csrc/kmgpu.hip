@@ -855,29 +855,9 @@ static int launch_graph_fast(km_batch* b, hipStream_t st) {
   return KM_OK;
 }
 
-// k_seed: KM_SEED_NS (1, 2 or 4) item records per wave group, KM_SEED_BLOCK (64, 128 or 256)
-// threads per block — the waves of a block do not cooperate
 static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
-  static const int ns = [] {
-    const char* e = getenv("KM_SEED_NS");
-    const int v = e ? atoi(e) : SEED_NS;
-    return (v == 1 || v == 2 || v == 4) ? v : SEED_NS;
-  }();
-  static const int bs = [] {
-    const char* e = getenv("KM_SEED_BLOCK");
-    const int v = e ? atoi(e) : (int)SEED_BLOCK;
-    return (v == 64 || v == 128 || v == 256) ? v : (int)SEED_BLOCK;
-  }();
-  const int wpb = bs / 64;
-  if (wa.stamps) {          // diagnostics build of the kernel (KM_SEED_STAMPS)
-    hipLaunchKernelGGL((k_seed<1, true>), dim3((n_items * 4 + wpb - 1) / wpb), dim3(bs), 0, st, wa);
-    return;
-  }
-  const uint32_t units = ((n_items + ns - 1) / ns) * 4;
-  const dim3 grid((units + wpb - 1) / wpb), block(bs);
-  if (ns == 1) hipLaunchKernelGGL((k_seed<1, false>), grid, block, 0, st, wa);
-  else if (ns == 2) hipLaunchKernelGGL((k_seed<2, false>), grid, block, 0, st, wa);
-  else hipLaunchKernelGGL((k_seed<4, false>), grid, block, 0, st, wa);
+  if (wa.stamps) hipLaunchKernelGGL(k_seed<true>, dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);   // KM_SEED_STAMPS diagnostics
+  else hipLaunchKernelGGL(k_seed<false>, dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
 }
 
 extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {

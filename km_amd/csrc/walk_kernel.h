@@ -238,8 +238,7 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
 }
 
 // ---------------------------------------------------------------------------- k_seed
-constexpr int SEED_NS = 2;   // item records per k_seed block
-// Diagnostic time stamps of k_seed (only when WalkArgs::stamps is set): every stamp first
+// Diagnostic time stamps of k_seed (only in the STAMPS instantiation): every stamp first
 // drains the outstanding loads, so the difference of two stamps is the full latency of the
 // stage between them.
 #define KM_SEED_STAMP(n)                                                                  \
@@ -252,208 +251,159 @@ constexpr int SEED_NS = 2;   // item records per k_seed block
     }                                                                                     \
   } while (0)
 
-// Sliding-window minimum over w consecutive selection keys, for the 64 + w positions a wave
-// needs: row[q] holds the key of base position q (q < 64 + w valid, the rest don't-care).
-// Log-step doubling between two ping-pong rows; KK = largest power of two <= w.
-constexpr uint32_t SCAN_ROW = 160;
-template <uint32_t KK>
-__device__ inline void scan_min(uint32_t (*buf)[SCAN_ROW], uint32_t lane, uint32_t W,
-                                uint32_t* m_child, uint32_t* m_first) {
-  uint32_t src = 0;
-#pragma unroll
-  for (uint32_t d = 1; d < KK; d <<= 1) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint32_t a0 = buf[src][lane], a1 = buf[src][lane + d];
-    const uint32_t e0 = buf[src][64 + lane], e1 = buf[src][64 + lane + d];
-    buf[src ^ 1][lane] = a0 < a1 ? a0 : a1;
-    buf[src ^ 1][64 + lane] = e0 < e1 ? e0 : e1;
-    src ^= 1;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const uint32_t m0 = buf[src][lane + 1], m1 = buf[src][lane + 1 + W - KK];
-  const uint32_t f0 = buf[src][0], f1 = buf[src][W - KK];
-  *m_child = m0 < m1 ? m0 : m1;      // (k-1)-mer starting at base q = lane + 1
-  *m_first = f0 < f1 ? f0 : f1;      // (k-1)-mer starting at base 0
-}
-
-// One lane per target k-mer ("seed"): its count, its get_child and the trivial / flagged
-// decision.  Every block works on NS item records at once and keeps the NS independent
-// chains  bases -> minimizer -> directory word -> slot  in flight together: the kernel is
-// bound by the latency of that chain, not by HBM bandwidth.
-template <int NS, bool STAMPS>
+// One block per item record (256 consecutive seeds of one target), one lane per seed: its
+// count, its get_child and the trivial / flagged decision.
+//
+// The kernel is bound by instruction issue, not by HBM (rocprof: the SIMDs issue ~75 % of
+// the time, 1.7 M line reads per launch), so the work per seed is kept minimal:
+//  * minimizers: every lane hashes ONE m-mer (the one starting at its base), the 256 + w keys
+//    go to LDS once, and a lane's minimizer is the minimum of the w keys after its own
+//    (one LDS round trip: w/2 ds_read2 + w/2 v_min3);
+//  * the lookup is key -> directory word -> the aligned home pair, three dependent loads with
+//    no loop (device_common.h: the build guarantees the pair).
+template <bool STAMPS>
 __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   static_assert(SEED_BLOCK == 256, "the item record holds 12 words = 256 seeds + k - 1 + 1 bases");
-  // per wave: two ping-pong rows of sliding-window keys (64 own positions + up to w beyond)
-  __shared__ uint32_t win[SEED_BLOCK / 64][2][SCAN_ROW];
-  const TableView tab = a.tab;
-  const int k = tab.k;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t (*buf)[SCAN_ROW] = win[threadIdx.x >> 6];
-  const uint32_t W = (uint32_t)tab.w;
-  const uint32_t K = 1u << (31 - __clz((int)W));           // largest power of two <= w
-  // Waves do not cooperate (any block size that is a multiple of 64 works).  Work unit gw =
-  // 64 seeds: four consecutive units share an item record; tid = this lane's seed within the
-  // record.  (A persistent grid-stride version was measured: the loop-carried uniforms cost
-  // 25 more VGPRs and it was 10 % slower.)
-  const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  {
+  constexpr uint32_t RAW = SEED_BLOCK + 32;                // selection keys of the item's m-mers
+  __shared__ uint32_t raw[RAW];
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long real0 = 0;
   uint32_t probes_first = 0;                               // diagnostics: slots read by this lane's lookup
   if constexpr (STAMPS) real0 = __builtin_amdgcn_s_memrealtime();
   KM_SEED_STAMP(0);
-  const uint32_t tid = ((gw & 3u) << 6) | lane;
-
-  const uint64_t* rec[NS];
-  bool live[NS];
-  uint32_t tgt[NS], idx0[NS], n_ref[NS];
-  uint64_t nb[NS], fwo[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const uint32_t item = (gw >> 2) * NS + s;
-    live[s] = item < a.n_items;
-    rec[s] = a.items + 16ull * (live[s] ? item : 0u);
-    const uint64_t h0 = rec[s][0], h1 = rec[s][1];
-    nb[s] = rec[s][2];
-    fwo[s] = rec[s][3];
-    live[s] = live[s] && (uint32_t)(h1 >> 32) != 0u;       // else: target not walkable (status != OK)
-    tgt[s] = (uint32_t)h0;
-    idx0[s] = (uint32_t)(h0 >> 32) + tid;                  // the first seed of an item is a multiple of 256
-    n_ref[s] = (uint32_t)h1;
-  }
+  const TableView tab = a.tab;
+  const int k = tab.k;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t W = (uint32_t)tab.w;
+  const uint64_t* rec = a.items + 16ull * blockIdx.x;
   KM_SEED_STAMP(1);
   // 64 bits of the target starting at item-relative base q
-  auto bits_at = [&](const uint64_t* r, uint32_t q) -> uint64_t {
+  auto bits_at = [&](uint32_t q) -> uint64_t {
     const uint32_t w = q >> 5, sh = (q & 31) * 2;
-    const uint64_t hi = r[4 + w], lo = r[5 + w];
+    const uint64_t hi = rec[4 + w], lo = rec[5 + w];
     return (hi << sh) | ((lo >> 1) >> (63 - sh));
   };
-  uint64_t x[NS], xe[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    x[s] = bits_at(rec[s], tid);
-    xe[s] = bits_at(rec[s], tid + 64);             // used by the lanes < w only
-  }
-
+  const uint64_t x = bits_at(tid);
   KM_SEED_STAMP(2);
-  // ---- minimizers of all (k-1)-mers of this wave's 64 seeds in one sliding-window scan:
-  // lane l owns the m-mer at wave-relative base q = l and (lanes < w) q = 64 + l; the
-  // minimizer of the (k-1)-mer starting at base q is the minimum over q .. q+w-1.
-  uint32_t u_child[NS], u_first[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    buf[0][lane] = mmer_scan_key(tab, x[s], lane);
-    buf[0][64 + lane] = mmer_scan_key(tab, xe[s], 64 + lane);
-    uint32_t mc, mf;
-    switch (K) {
-      case 16: scan_min<16>(buf, lane, W, &mc, &mf); break;
-      case 8: scan_min<8>(buf, lane, W, &mc, &mf); break;
-      case 4: scan_min<4>(buf, lane, W, &mc, &mf); break;
-      case 2: scan_min<2>(buf, lane, W, &mc, &mf); break;
-      default: scan_min<1>(buf, lane, W, &mc, &mf); break;
-    }
-    u_child[s] = (mc & SEL_POS) - (lane + 1);
-    u_first[s] = mf & SEL_POS;
-  }
 
+  // ---- minimizers.  raw[q] = selection key of the m-mer starting at base q; the (k-1)-mer
+  // starting at base q has the windows q .. q+w-1.  This lane needs X[1:] (base tid + 1).
+  raw[tid] = mmer_scan_key(tab, x, tid);
+  if (tid < W) raw[SEED_BLOCK + tid] = mmer_scan_key(tab, bits_at(SEED_BLOCK + tid), SEED_BLOCK + tid);
+  // the record header is only needed from here on: its load overlapped the bases above
+  const uint64_t h0 = rec[0], h1 = rec[1];
+  const uint64_t nb = rec[2], fwo = rec[3];
+  if ((uint32_t)(h1 >> 32) == 0u) return;                  // target not walkable (status != OK); block-uniform
+  const uint32_t t = (uint32_t)h0;
+  const uint32_t n_ref = (uint32_t)h1;
+  const uint32_t i = (uint32_t)(h0 >> 32) + tid;           // the first seed of an item is a multiple of 256
+  __syncthreads();
+  uint32_t m_rest;                                         // min over bases tid+1 .. tid+w-1
+  uint32_t m_last;                                         // key of base tid+w
+  if (W == 16) {
+    const uint32_t* r = raw + tid + 1;
+    const uint32_t m0 = min(min(r[0], r[1]), r[2]), m1 = min(min(r[3], r[4]), r[5]);
+    const uint32_t m2 = min(min(r[6], r[7]), r[8]), m3 = min(min(r[9], r[10]), r[11]);
+    const uint32_t m4 = min(min(r[12], r[13]), r[14]);
+    m_rest = min(min(min(m0, m1), m2), min(m3, m4));
+    m_last = r[15];
+  } else {
+    m_rest = ~0u;
+    for (uint32_t j = 1; j < W; ++j) m_rest = min(m_rest, raw[tid + j]);
+    m_last = raw[tid + W];
+  }
+  const uint32_t u_child = (min(m_rest, m_last) & SEL_POS) - (tid + 1);
   KM_SEED_STAMP(3);
-  // ---- keys, directory words, first two probe slots: all loads of a stage are issued
-  // together.  The wave holding seed 0 of a target also needs query(ref[0]) (its (k-1)-mer
-  // prefix starts at base 0); that lookup rides along as one more independent chain.
-  uint64_t X[NS], S[NS], pos[NS], Sq[NS], posq[NS];
-  Key g[NS], gq[NS];
-  DirPair dw[NS], dq[NS];
-  const Slot* base[NS];
-  const Slot* baseq[NS];
-  uint4 first[NS], second[NS], firstq[NS], secondq[NS];
-  bool head[NS];                                           // wave-uniform: this wave holds seed 0
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    X[s] = x[s] >> (64 - 2 * k);
-    g[s] = key_from_window(tab, X[s] & tab.pmask, u_child[s]);
-    dw[s] = *reinterpret_cast<const DirPair*>(tab.dir + g[s].bucket);
-    head[s] = idx0[s] == lane;
-    if (head[s]) {
-      gq[s] = key_from_window(tab, X[s] >> 2, u_first[s]);
-      dq[s] = *reinterpret_cast<const DirPair*>(tab.dir + gq[s].bucket);
-    }
+
+  // ---- key, directory word, home pair.  Thread 0 of a target's first item also needs
+  // query(ref[0]) (its (k-1)-mer prefix starts at base 0): one more independent chain.
+  const uint64_t X = x >> (64 - 2 * k);
+  const Key g = key_from_window(tab, X & tab.pmask, u_child);
+  const DirPair dw = *reinterpret_cast<const DirPair*>(tab.dir + g.bucket);
+  const bool head = i == 0;
+  Key gq = g;
+  DirPair dq = dw;
+  if (head) {
+    const uint32_t u_first = min(raw[0], m_rest) & SEL_POS;
+    gq = key_from_window(tab, X >> 2, u_first);
+    dq = *reinterpret_cast<const DirPair*>(tab.dir + gq.bucket);
   }
   KM_SEED_STAMP(4);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    S[s] = bucket_slots(dw[s].lo, dw[s].hi);
-    base[s] = tab.slots + 2ull * dw[s].lo;
-    pos[s] = home_slot(tab, g[s], S[s]);                   // 0 for an empty bucket
-    // the home pair, loaded unconditionally (an empty bucket reads some valid slots and
-    // ignores them): keeps the loads independent of each other
-    const Slot* b0 = S[s] ? base[s] : tab.slots;
-    first[s] = *reinterpret_cast<const uint4*>(b0 + pos[s]);
-    second[s] = *reinterpret_cast<const uint4*>(b0 + pos[s] + 1);
-    if (head[s]) {
-      Sq[s] = bucket_slots(dq[s].lo, dq[s].hi);
-      baseq[s] = tab.slots + 2ull * dq[s].lo;
-      posq[s] = home_slot(tab, gq[s], Sq[s]);
-      const Slot* bq = Sq[s] ? baseq[s] : tab.slots;
-      firstq[s] = *reinterpret_cast<const uint4*>(bq + posq[s]);
-      secondq[s] = *reinterpret_cast<const uint4*>(bq + posq[s] + 1);
+  const uint32_t S = (uint32_t)bucket_slots(dw.lo, dw.hi);
+  const Slot* base = tab.slots + 2ull * dw.lo;
+  const uint32_t pos = (uint32_t)home_slot(tab, g, S);     // 0 for an empty bucket
+  // loaded unconditionally (an empty bucket reads some valid slots and ignores them)
+  const Slot* b0 = (S ? base : tab.slots) + pos;
+  const uint4 first = *reinterpret_cast<const uint4*>(b0);
+  const uint4 second = *reinterpret_cast<const uint4*>(b0 + 1);
+  uint32_t Sq = 0, posq = 0;
+  const Slot* baseq = tab.slots;
+  uint4 firstq = first, secondq = second;
+  if (head) {
+    Sq = (uint32_t)bucket_slots(dq.lo, dq.hi);
+    baseq = tab.slots + 2ull * dq.lo;
+    posq = (uint32_t)home_slot(tab, gq, Sq);
+    const Slot* bq = (Sq ? baseq : tab.slots) + posq;
+    firstq = *reinterpret_cast<const uint4*>(bq);
+    secondq = *reinterpret_cast<const uint4*>(bq + 1);
+  }
+  KM_SEED_STAMP(5);
+
+  uint32_t fetch_l = 0;
+  bool valid = false, triv = false, triv_child = false;
+  if (i < n_ref) {
+    valid = true;
+    uint4 c4 = make_uint4(0, 0, 0, 0);
+    if (S) c4 = bucket_resolve2(tab, g, base, S, pos, first, second, &fetch_l);
+    c4 = finish_children(tab, X, g.flip, c4);
+    KM_SEED_STAMP(6);
+    if constexpr (STAMPS) probes_first = fetch_l;
+    a.node_kmer[nb + i] = X;
+    uint32_t nextb = 4;
+    if (i + 1 < n_ref) {
+      // last base of ref[i+1] = base k of this lane's 32-base window (k <= 31), else reloaded
+      if (k < 32) {
+        nextb = (uint32_t)(x >> (62 - 2 * k)) & 3u;
+      } else {
+        const uint32_t p = tid + (uint32_t)k;
+        nextb = (uint32_t)(rec[4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
+      }
+      a.node_cnt[nb + i + 1] = pick4(c4, nextb);
+    }
+    if (head) {                                            // node_data[ref[0]] = jf.query(ref[0])
+      uint4 cq = make_uint4(0, 0, 0, 0);
+      if (Sq) cq = bucket_resolve2(tab, gq, baseq, Sq, posq, firstq, secondq, &fetch_l);
+      const uint32_t sb = (uint32_t)(X & 3);
+      uint32_t v = pick4(cq, gq.flip ? 3 - sb : sb);
+      if (v == COUNT_ESCAPE) v = overflow_count(tab, X);
+      a.node_cnt[nb] = v;
+    }
+    if (a.max_stack > 0) {
+      const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
+      triv = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
+      triv_child = triv && mask != 0;
+      if (!triv) {
+        atomicOr(&a.flagbits[fwo + (i >> 5)], 1u << (i & 31));
+        if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
+      }
     }
   }
-
-  KM_SEED_STAMP(5);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    if (!live[s]) continue;                                // block-uniform
-    const uint32_t i = idx0[s], t = tgt[s];
-    uint32_t fetch_l = 0;
-    bool valid = false, triv = false, triv_child = false;
-    if (i < n_ref[s]) {
-      valid = true;
-      uint4 c4 = make_uint4(0, 0, 0, 0);
-      if (S[s]) c4 = bucket_resolve2(tab, g[s], base[s], S[s], pos[s], first[s], second[s], &fetch_l);
-      c4 = finish_children(tab, X[s], g[s].flip, c4);
-      if (s == 0) KM_SEED_STAMP(6);
-      if constexpr (STAMPS) { if (s == 0) probes_first = fetch_l; }
-      a.node_kmer[nb[s] + i] = X[s];
-      uint32_t nextb = 4;
-      if (i + 1 < n_ref[s]) {
-        // last base of ref[i+1] = base k of this lane's 32-base window (k <= 31), else reloaded
-        if (k < 32) {
-          nextb = (uint32_t)(x[s] >> (62 - 2 * k)) & 3u;
-        } else {
-          const uint32_t p = tid + (uint32_t)k;
-          nextb = (uint32_t)(rec[s][4 + (p >> 5)] >> (62 - 2 * (p & 31))) & 3u;
-        }
-        a.node_cnt[nb[s] + i + 1] = pick4(c4, nextb);
-      }
-      if (i == 0) {                                        // node_data[ref[0]] = jf.query(ref[0])
-        uint4 cq = make_uint4(0, 0, 0, 0);
-        if (Sq[s]) cq = bucket_resolve2(tab, gq[s], baseq[s], Sq[s], posq[s], firstq[s], secondq[s], &fetch_l);
-        const uint32_t sb = (uint32_t)(X[s] & 3);
-        uint32_t v = pick4(cq, gq[s].flip ? 3 - sb : sb);
-        if (v == COUNT_ESCAPE) v = overflow_count(tab, X[s]);
-        a.node_cnt[nb[s]] = v;
-      }
-      if (a.max_stack > 0) {
-        const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
-        triv = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
-        triv_child = triv && mask != 0;
-        if (!triv) {
-          atomicOr(&a.flagbits[fwo[s] + (i >> 5)], 1u << (i & 31));
-          if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
-        }
-      }
-    }
-    // one atomic per wave for the per-target counters.  Logical probes per seed:
-    // node_data[s] = jf.query(s) (1); for a trivial seed also get_child (4) and the
-    // re-query of [seed] when it has a child (1)
-    const unsigned long long probes_w = (unsigned long long)__popcll(__ballot(valid)) +
-                                        4ull * __popcll(__ballot(triv)) + __popcll(__ballot(triv_child));
-    for (int o = 32; o > 0; o >>= 1) fetch_l += __shfl_xor(fetch_l, o);
-    if (lane == 0 && probes_w) {
-      atomicAdd(&a.probes[t], probes_w);
-      atomicAdd(&a.fetches[t], (unsigned long long)fetch_l);
-    }
+  // one atomic per wave for the per-target counters.  Logical probes per seed:
+  // node_data[s] = jf.query(s) (1); for a trivial seed also get_child (4) and the
+  // re-query of [seed] when it has a child (1).  Slots read: 1 or 2 per lookup, more only in
+  // a table whose build gave up the pair bound.
+  const unsigned long long probes_w = (unsigned long long)__popcll(__ballot(valid)) +
+                                      4ull * __popcll(__ballot(triv)) + __popcll(__ballot(triv_child));
+  unsigned long long fetch_w = (unsigned long long)__popcll(__ballot(fetch_l >= 1)) + __popcll(__ballot(fetch_l >= 2));
+  if (__any(fetch_l > 2)) {
+    uint32_t extra = fetch_l > 2 ? fetch_l - 2 : 0;
+    for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o);
+    fetch_w += extra;
+  }
+  if (lane == 0 && probes_w) {
+    atomicAdd(&a.probes[t], probes_w);
+    atomicAdd(&a.fetches[t], fetch_w);
   }
   if constexpr (STAMPS) {
     KM_SEED_STAMP(7);
@@ -465,14 +415,13 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
       psum += __shfl_xor(psum, o2);
     }
     if (lane == 0) {
-      unsigned long long* o = a.stamps + 16ull * gw;
+      unsigned long long* o = a.stamps + 16ull * (blockIdx.x * (SEED_BLOCK / 64) + (tid >> 6));
       for (int q = 0; q < 8; ++q) o[q] = ts[q];
       o[8] = real0; o[9] = real1;
       o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave, SIMD, CU, SH, SE
       o[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
       o[12] = pmax; o[13] = psum;
     }
-  }
   }
 }
 
