@@ -115,10 +115,11 @@ __host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap)
 // and the last k-mer's suffix not among them — and if so emit its single path.  Small LDS
 // (prefix keys only), so it runs at full occupancy and overlaps k_dfs on a second stream.
 // Everything else is left to k_graph through need_full[].
-__global__ __launch_bounds__(GRAPH_THREADS) void k_graph_pure(GraphArgs a) {
+__global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const uint32_t tid = threadIdx.x, NT = GRAPH_THREADS;
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  // one wave per target: this pass runs beside k_dfs, it should take few wave slots
+  const uint32_t lane = threadIdx.x & 63u, NT = 64;
+  const uint32_t tid = lane;
   const uint32_t t = blockIdx.x;
   if (a.status[t] != T_OK) {
     if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
@@ -142,10 +143,13 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph_pure(GraphArgs a) {
   }
   __syncthreads();
   uint32_t not_pure = 0;
+  uint32_t mincov = 0xFFFFFFFFu;
   for (uint32_t j = tid; j < n_ref; j += NT) {
     bool wn;
     const int s = set_insert_lane(pkeys, hcap, nk[j] >> 2, &wn);
     if (s < 0 || !wn) not_pure = 1;
+    const uint32_t c = ncnt[j];
+    mincov = c < mincov ? c : mincov;
   }
   __syncthreads();
   if (tid == 0 && !not_pure) {
@@ -158,13 +162,10 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph_pure(GraphArgs a) {
       if (++s == hcap) s = 0;
     }
   }
-  if (__syncthreads_or((int)not_pure)) {
+  if (__any((int)not_pure)) {
     if (tid == 0) a.need_full[t] = 1;
     return;
   }
-  if (wave != 0) return;
-  uint32_t mincov = 0xFFFFFFFFu;
-  for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
   for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
   if (lane == 0) {
     const uint32_t pg = t % POOL_GROUPS;

@@ -844,7 +844,7 @@ static int launch_graph_fast(km_batch* b, hipStream_t st) {
   if (b->fast_ok) {
     pure_geometry(b);
     b->ga.use_need_full = 1;
-    hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(GRAPH_THREADS), b->pure_lds, st, b->ga);
+    hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, st, b->ga);
     hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, b->ga);
   } else {
     // no LDS-resident tier for these parameters: mark everything for the large tier
@@ -936,7 +936,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
       HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
       pure_geometry(b);
       ga.use_need_full = 1;
-      hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(GRAPH_THREADS), b->pure_lds, b->side, ga);
+      hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, b->side, ga);
       HIPCHK(hipEventRecord(e_join, b->side));
       hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
       HIPCHK(hipGetLastError());
