@@ -58,9 +58,10 @@ typedef struct {
   uint64_t n_records;    /* records held (count > 0)                          */
   uint64_t n_slots;      /* device table capacity in 16-byte slots (0 = not uploaded) */
   uint64_t n_groups;     /* occupied slots                                    */
-  uint64_t table_bytes;  /* n_slots * 16 + side table of counts >= 65535      */
+  uint64_t table_bytes;  /* n_slots * 16 + bucket directory + side table of counts >= 65535 */
   int32_t  device;       /* HIP device ordinal of the table, -1 if none       */
-  int32_t  reserved;
+  int32_t  max_probe;    /* slots a lookup may read: 2 (the home pair) unless a minimizer
+                            bucket was too heavy to keep that bound            */
 } kmjf_info_t;
 
 /* Walk parameters = the CLI flags of km/argparser/find_mutation.py:5-39 as they

@@ -198,7 +198,7 @@ extern "C" int kmjf_info(const kmjf_t* h, kmjf_info_t* info) {
   info->table_bytes = h->n_slots * sizeof(Slot) + h->n_ovf * sizeof(OvfSlot) +
                       (h->d_dir ? ((uint64_t)h->n_buckets + 1) * 4 : 0);
   info->device = h->device;
-  info->reserved = 0;
+  info->max_probe = h->d_slots ? (int32_t)h->max_probe : 0;
   return KM_OK;
 }
 
@@ -283,14 +283,13 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   }
   hipLaunchKernelGGL(k_dir_capacity, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
                      (uint64_t)n_buckets, unit, tv.cshift);
-  const int MAX_ROUNDS = 12;
-  const uint64_t GROW_LIMIT = 4096;     // slots: a heavier bucket probes linearly instead of doubling
+  const int MAX_ROUNDS = 4;             // CAP_MAX_GEN doublings + 1, then one final round just in case
   unsigned long long meta[6] = {0, 0, 0, 0, 0, 0};
   uint64_t n_slots = 0;
   uint32_t max_probe = 2;
   int rounds = 0;
   for (;; ++rounds) {
-    const uint64_t grow_limit = rounds < MAX_ROUNDS ? GROW_LIMIT : 0;
+    const int final_round = rounds >= MAX_ROUNDS;
     (void)hipMemsetAsync(d_meta, 0, 32, st);          // [0..3]
     (void)hipMemsetAsync(d_meta + 5, 0, 8, st);
     hipLaunchKernelGGL(k_dir_copy, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps, dir,
@@ -314,7 +313,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
     if (n)
       hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, slots, d_keys,
-                         d_counts, n, caps, grow_limit, d_meta);
+                         d_counts, n, caps, final_round, d_meta);
     e = hipMemcpyAsync(meta, d_meta, 32, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return bail(KM_E_HIP, "table build failed", e);
@@ -323,7 +322,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     if (getenv("KM_BUILD_VERBOSE"))
       fprintf(stderr, "libkmgpu: build round %d: %llu slots, %llu buckets to grow, max distance %llu\n", rounds,
               (unsigned long long)n_slots, meta[2], meta[3]);
-    if (!grow_limit) break;
+    if (final_round) break;
     if (meta[2] == 0) break;
     hipLaunchKernelGGL(k_dir_grow, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
                        (uint64_t)n_buckets, tv.cshift);

@@ -57,23 +57,36 @@ __device__ inline uint64_t shape_capacity(uint64_t cap, uint64_t NC) {
   if (cap >= NC) cap = (cap + 2 * NC - 1) / (2 * NC) * (2 * NC);
   return cap;
 }
-constexpr uint32_t CAP_GROW = 0x80000000u;   // flag in caps[]: some key did not fit its home pair
+// caps[] word: capacity in units of 2 slots (29 bits), how often the bucket was doubled
+// (2 bits), and the flag "some key did not fit its home pair in this round".
+constexpr uint32_t CAP_GROW = 0x80000000u;
+constexpr uint32_t CAP_GEN_SHIFT = 29;
+constexpr uint32_t CAP_SIZE = (1u << CAP_GEN_SHIFT) - 1;
+constexpr uint32_t CAP_MAX_GEN = 2;          // doublings per bucket (load 1/2 -> 1/8), then it probes
+__device__ inline uint32_t cap_gen(uint32_t c) { return (c >> CAP_GEN_SHIFT) & 3u; }
 
 // Entry count -> initial capacity, in place.
 __global__ void k_dir_capacity(uint32_t* caps, uint64_t n, uint32_t unit, uint32_t cshift) {
   const uint64_t NC = 1ull << cshift;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (uint64_t)gridDim.x * blockDim.x)
-    caps[i] = (uint32_t)(shape_capacity((uint64_t)caps[i] * unit, NC) >> 1);
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t pairs = shape_capacity((uint64_t)caps[i] * unit, NC) >> 1;
+    // a bucket too large for the size field starts saturated (it could not double anyway)
+    caps[i] = pairs > CAP_SIZE / 8 ? (uint32_t)(pairs > CAP_SIZE ? CAP_SIZE : pairs) | (CAP_MAX_GEN << CAP_GEN_SHIFT)
+                                   : (uint32_t)pairs;
+  }
 }
 
-// Double every flagged bucket (and clear its flag).
+// Double every flagged bucket that may still grow (and clear the flags).
 __global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift) {
   const uint64_t NC = 1ull << cshift;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t c = caps[i];
-    if (c & CAP_GROW) caps[i] = (uint32_t)(shape_capacity(4ull * (c & ~CAP_GROW), NC) >> 1);
+    if (!(c & CAP_GROW)) continue;
+    const uint32_t gen = cap_gen(c);
+    const uint64_t pairs = shape_capacity(4ull * (c & CAP_SIZE), NC) >> 1;
+    caps[i] = (uint32_t)pairs | ((gen + 1) << CAP_GEN_SHIFT);
   }
 }
 
@@ -83,7 +96,7 @@ __global__ void k_dir_copy(const uint32_t* caps, uint32_t* dir, uint64_t n,
   unsigned long long local = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = caps[i] & ~CAP_GROW;
+    const uint32_t c = caps[i] & CAP_SIZE;
     dir[i] = c;
     local += c;
   }
@@ -190,12 +203,13 @@ __global__ void k_ovf_insert(const uint64_t* keys, const uint32_t* counts, uint6
 // Insert pass: one record per thread, entered under the group of each orientation into the
 // home pair of its bucket.  A key whose home pair is taken flags its bucket in caps[]
 // (meta[2] counts flagged buckets) — the host doubles those buckets and rebuilds — unless the
-// bucket already holds grow_limit slots or more: such a heavy bucket (a minimizer shared by
-// very many k-mers) keeps probing linearly instead, and meta[3] records the largest probe
-// distance used.  meta[0] counts occupied slots, meta[1] != 0 reports a full bucket.
+// bucket has used up its doublings (a minimizer shared by very many similar k-mers: real
+// data at high coverage) or this is the final round (final != 0): then the key probes on
+// linearly and meta[3] records the largest probe distance used.  meta[0] counts occupied
+// slots, meta[1] != 0 reports a full bucket.
 __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
-                               const uint32_t* counts, uint64_t n, uint32_t* caps,
-                               uint64_t grow_limit, unsigned long long* meta) {
+                               const uint32_t* counts, uint64_t n, uint32_t* caps, int final,
+                               unsigned long long* meta) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t K = keys[i];
@@ -212,9 +226,10 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
       const uint64_t S = bucket_slots(lo, hi);
       Slot* base = slots + 2ull * lo;
       uint64_t idx = home_slot(t, g, S);
+      const bool may_grow = !final && cap_gen(caps[g.bucket]) < CAP_MAX_GEN;
       bool done = false;
       for (uint64_t step = 0; step < S; ++step) {
-        if (step == 2 && S < grow_limit) break;         // the pair is taken: grow this bucket
+        if (step == 2 && may_grow) break;               // the pair is taken: grow this bucket
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&base[idx].tag),
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
         if (old == EMPTY) atomicAdd(&meta[0], 1ull);
@@ -227,7 +242,7 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
         if (++idx == S) idx = 0;
       }
       if (!done) {
-        if (S < grow_limit) {
+        if (may_grow) {
           if (!(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW)) atomicAdd(&meta[2], 1ull);
         } else {
           atomicExch(reinterpret_cast<unsigned int*>(&meta[1]), 1u);

@@ -37,7 +37,7 @@ class KmError(RuntimeError):
 class JfInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("canonical", C.c_int32), ("n_records", C.c_uint64),
                 ("n_slots", C.c_uint64), ("n_groups", C.c_uint64), ("table_bytes", C.c_uint64),
-                ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("max_probe", C.c_int32)]
 
 
 class Params(C.Structure):

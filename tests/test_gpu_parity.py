@@ -104,6 +104,76 @@ def test_children_backward_matches_oracle():
         assert jf.get_child(s, forward=False) == db.get_child(s, forward=False)
 
 
+def test_heavy_minimizer_bucket_falls_back_to_probing():
+    """The table build keeps every key inside its aligned home pair by doubling crowded
+    buckets; a minimizer shared by thousands of k-mers is too heavy for that and falls back to
+    linear probing (info.max_probe > 2).  Lookups must stay exact on both paths."""
+    rng = np.random.default_rng(77)
+    k, m = 31, 15
+    # an m-mer whose order hash (device_common.h: mm_order) is tiny: it is the minimizer of
+    # every (k-1)-mer that contains it
+    cand = np.arange(1, 1 << 22, dtype=np.uint64)
+    cand = cand[cand <= jr.revcomp_np(cand, m)]                           # canonical m-mers only
+    order = (cand * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    mm = int(cand[int(np.argmin(order >> np.uint64(9)))])
+    n_heavy = 6000
+    base = rng.integers(0, 1 << 62, size=n_heavy, dtype=np.uint64)
+    off = rng.integers(1, k - m - 1, size=n_heavy).astype(np.uint64)        # inside both (k-1)-mers
+    shift = np.uint64(2) * (np.uint64(k - m) - off)
+    mask = (np.uint64((1 << (2 * m)) - 1)) << shift
+    heavy = (base & ~mask) | (np.uint64(mm) << shift)
+    bg = rng.integers(0, 1 << 62, size=20000, dtype=np.uint64)
+    keys = np.unique(np.array([jr.canonical(int(x), k) for x in np.concatenate([heavy, bg])], dtype=np.uint64))
+    counts = rng.integers(1, 60000, size=len(keys)).astype(np.uint32)
+    counts[:5] = np.array([65535, 70000, 1, 0xFFFFFFFF, 65534], dtype=np.uint32)
+    db = kmlib.Database.from_records(keys, counts, k).upload(0)
+    assert db.info.max_probe > 2, "the heavy bucket should have given up the pair bound"
+    assert (db.query(keys) == counts).all()
+    assert (db.query(jr.revcomp_np(keys, k)) == counts).all()
+    table = dict(zip(keys.tolist(), counts.tolist()))
+    # absent k-mers that still land in the heavy bucket: one base changed
+    near = heavy[:3000] ^ np.uint64(1)
+    want = np.array([table.get(jr.canonical(int(x), k), 0) for x in near], dtype=np.uint32)
+    assert (db.query(near) == want).all()
+    # get_child through the same table
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    probe = heavy[:2000]
+    _, c4 = jf.children_many(probe)
+    kmask = (1 << (2 * k)) - 1
+    for i in range(0, 2000, 37):
+        x = int(probe[i])
+        for c in range(4):
+            child = ((x << 2) | c) & kmask
+            assert int(c4[i][c]) == table.get(jr.canonical(child, k), 0)
+    # an ordinary synthetic batch beside the heavy bucket (every lookup now loops to max_probe)
+    case = synth.make_case(n_targets=30, length=200, n_keys=20_000, seed=5, variant_frac=0.7)
+    allk = np.concatenate([case["keys"], keys])
+    allc = np.concatenate([case["counts"], counts])
+    allk, first = np.unique(allk, return_index=True)
+    allc = allc[first]
+    db2 = kmlib.Database.from_records(allk, allc, k).upload(0)
+    assert db2.info.max_probe > 2
+    jf2 = Jellyfish("mem2.jf", cutoff=0.05, n_cutoff=5, db=db2)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                    records={"k": k, "canonical": True, "keys": allk, "counts": allc})
+    _compare_with_oracle(jf2, cpu, [(n, km.decode(r)) for n, r in zip(case["names"], case["targets"])])
+
+
+def test_table_build_bounds_memory_and_probe_length():
+    """Real sequencing data puts many near-identical super-k-mers behind one minimizer: such
+    buckets double at most twice and then probe; the table stays within a few slots per group
+    and lookups within a handful of probes."""
+    for name in DBS[:2]:
+        jf = Jellyfish("./data/jf/" + name)
+        info = jf.db.info
+        assert 2 <= info.max_probe <= 64
+        assert info.n_groups <= 2 * info.n_records
+        assert 2 * info.n_groups <= info.n_slots <= 40 * info.n_groups
+    case = synth.make_case(n_targets=50, length=300, n_keys=200_000, seed=9)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    assert db.info.n_slots <= 12 * db.info.n_groups
+
+
 # ------------------------------------------------------------------ walk + graph
 def _compare_with_oracle(jf_gpu, db_cpu, targets, steps=500, branchs=10, nodes=10000):
     finder = BatchFinder(jf_gpu, steps, branchs, nodes)
