@@ -129,15 +129,20 @@ def main():
     case = None
     if rank == 0:
         tag = "%s/case_%d_%d_%d" % (args.cache, T * world, args.length, args.keys)
+        fields = ("keys", "counts", "targets", "key_target")
         if args.cache and os.path.exists(tag + "_keys.npy"):
-            case = {f: np.load("%s_%s.npy" % (tag, f)) for f in ("keys", "counts", "targets")}
+            case = {f: np.load("%s_%s.npy" % (tag, f)) for f in fields}
+            meta = json.load(open(tag + "_meta.json"))
+            case.update(k=K, n_real=meta["n_real"], names=meta["names"])
         else:
             case = synth.make_case(n_targets=T * world, length=args.length, k=K, n_keys=args.keys,
                                    seed=synth.HEADLINE_SEED, exact_pad=False)
             if args.cache:
                 os.makedirs(args.cache, exist_ok=True)
-                for f in ("keys", "counts", "targets"):
+                for f in fields:
                     np.save("%s_%s.npy" % (tag, f), case[f])
+                json.dump({"n_real": int(case["n_real"]), "names": list(case["names"])},
+                          open(tag + "_meta.json", "w"))
     t_gen = time.perf_counter() - t_gen
 
     # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------

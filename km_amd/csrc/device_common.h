@@ -205,11 +205,19 @@ __device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
   uint32_t c = 0, s = 0;
   uint32_t mine = ~0u;
   if (lane < t.w) mine = window_key(t, P, R, lane, &c, &s);
-  uint32_t best = ~0u;
-  for (int j = 0; j < t.w; ++j) {
-    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-    best = v < best ? v : best;
+  // minimum over the lanes < w (w <= 17): a row_shr DPP tree leaves each 16-lane row's
+  // minimum in its last lane
+  uint32_t v = mine;
+  {
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xF, 0xF, false); v = o < v ? o : v;
   }
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+  const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+  const uint32_t best = b0 < b1 ? b0 : b1;
   const int u = (int)(best & SEL_POS);
   const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, u);
   const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)s, u);
@@ -346,20 +354,48 @@ __device__ inline uint4 forward_children(const TableView& t, uint64_t X, uint32_
   return forward_children_keyed(t, X, make_key(t, X & t.pmask), fetches);
 }
 
-// The same for a wave-uniform X (k_dfs): key computed across the lanes, and the directory
-// word of the last bucket kept in registers — consecutive walk steps mostly stay in it.
+// The same for a wave-uniform X (k_dfs), split in two so that the loads of the NEXT walk step
+// can be in flight while the current one is still being booked: issue (key computed across
+// the lanes; the directory word of the last bucket is kept in registers — consecutive walk
+// steps mostly stay in it; the home pair is requested) and finish (compare, child order).
 struct DirCache { uint32_t bucket, lo, hi; };
+struct PendingLookup {
+  uint64_t X;        // k-mer whose forward children were requested
+  Key g;
+  const Slot* base;
+  uint64_t S, idx;
+  uint4 a0, a1;
+  bool valid;
+};
+__device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCache* dc,
+                                           PendingLookup* p) {
+  p->X = X;
+  p->g = make_key_wave(t, X & t.pmask);
+  if (p->g.bucket != dc->bucket) {
+    const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + p->g.bucket);
+    dc->bucket = p->g.bucket; dc->lo = d.lo; dc->hi = d.hi;
+  }
+  p->S = bucket_slots(dc->lo, dc->hi);
+  p->base = t.slots + 2ull * dc->lo;
+  p->idx = home_slot(t, p->g, p->S);
+  const Slot* b0 = (p->S ? p->base : t.slots) + p->idx;
+  p->a0 = *reinterpret_cast<const uint4*>(b0);
+  p->a1 = *reinterpret_cast<const uint4*>(b0 + 1);
+  p->valid = true;
+}
+__device__ inline uint4 children_finish_wave(const TableView& t, const PendingLookup& p,
+                                             uint32_t* fetches) {
+  uint4 c = make_uint4(0, 0, 0, 0);
+  if (p.S) c = bucket_resolve2(t, p.g, p.base, p.S, p.idx, p.a0, p.a1, fetches);
+  return finish_children(t, p.X, p.g.flip, c);
+}
 __device__ inline uint4 forward_children_wave(const TableView& t, uint64_t X, DirCache* dc,
                                               uint32_t* fetches) {
-  const Key g = make_key_wave(t, X & t.pmask);
-  if (g.bucket != dc->bucket) {
-    const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + g.bucket);
-    dc->bucket = g.bucket; dc->lo = d.lo; dc->hi = d.hi;
-  }
-  return finish_children(t, X, g.flip, bucket_lookup4(t, g, dc->lo, dc->hi, fetches));
+  PendingLookup p;
+  children_issue_wave(t, X, dc, &p);
+  return children_finish_wave(t, p, fetches);
 }
 
-// Jellyfish.query(X): km/utils/Jellyfish.py:47-53.
 // g = key of X[:-1]
 __device__ inline uint32_t query_one_keyed(const TableView& t, uint64_t X, const Key& g,
                                            uint32_t* fetches) {

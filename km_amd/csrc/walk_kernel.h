@@ -502,6 +502,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   uint32_t st = T_OK;
   uint32_t n_nodes = n_ref;
   DirCache dcache = {~0u, 0u, 0u};
+  PendingLookup pend;
+  pend.valid = false;
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
@@ -530,7 +532,9 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           if (need_expand) {
             need_expand = false;
             if (n_nodes > a.max_node) { st = T_NODE_LIMIT; break; }
-            c4 = forward_children_wave(tab, cur, &dcache, &fetch_u);
+            if (!(pend.valid && pend.X == cur)) children_issue_wave(tab, cur, &dcache, &pend);
+            c4 = children_finish_wave(tab, pend, &fetch_u);
+            pend.valid = false;
             probes_u += 4;
             mask = child_mask(c4, a.ratio, a.n_cutoff);
             brk = parent_brk;
@@ -538,6 +542,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               ++brk;
               if (brk > a.max_break) mask = 0;
             }
+            // the walk most likely continues with the first kept child: request its lookup
+            // now, its latency overlaps the bookkeeping of this step
+            if (mask && depth + 1 <= a.max_stack)
+              children_issue_wave(tab, ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask, &dcache, &pend);
           }
           if (mask == 0) {
             if (bsp == 0) break;                         // DFS from this seed is done

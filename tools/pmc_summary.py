@@ -21,7 +21,7 @@ for kname, ctrs in agg.items():
     out[kname] = {c: sum(v) / len(v) for c, v in ctrs.items()}
     out[kname]["dispatches"] = len(next(iter(ctrs.values())))
 res = {"per_kernel_avg_per_dispatch": out}
-ks = out.get("k_seed")
+ks = next((v for k_, v in out.items() if k_.startswith("k_seed")), None)
 if ks and "TCC_EA0_RDREQ_sum" in ks:
     r128 = ks.get("TCC_EA0_RDREQ_128B_sum", 0.0)
     r32 = ks.get("TCC_EA0_RDREQ_32B_sum", 0.0)
