@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay each step as one captured hipGraph (measured: no gain, GPU-bound)")
     ap.add_argument("--walk-only", action="store_true", help="time the walk stage only (ablations)")
+    ap.add_argument("--only-step", action="store_true",
+                    help="skip the side measurements (end-to-end host path, probe kernels, one-target "
+                         "latency): every launch in a profile of this run is a 10 000-target launch")
     ap.add_argument("--cache", default="", help="directory to keep the generated workload in "
                     "(re-used by later invocations with the same sizes)")
     ap.add_argument("--inflight", type=int, default=4,
@@ -250,7 +253,7 @@ def main():
 
     # ---- end to end through the drop-in host path: strings -> GPU -> TSV rows -----------
     e2e = None
-    if rank == 0 and args.e2e > 0:
+    if rank == 0 and args.e2e > 0 and not args.only_step:
         from km_amd import kmer as km, report
         from km_amd.finder import BatchFinder
         from km_amd.jellyfish import Jellyfish
@@ -268,7 +271,7 @@ def main():
     # ---- probe kernels alone (rows A2 / A3): Jellyfish.query and get_child for a resident
     #      array of stored k-mers in random order; 12 resp. 48 algorithmic bytes per element
     probe = None
-    if rank == 0 and d_probe is not None:
+    if rank == 0 and d_probe is not None and not args.only_step:
         d_out = torch.empty(n_probe, dtype=torch.int32, device=dev)
         d_mask = torch.empty(n_probe, dtype=torch.uint8, device=dev)
         d_c4 = torch.empty((n_probe, 4), dtype=torch.int32, device=dev)
@@ -299,7 +302,7 @@ def main():
     single = None
     fix_fa = os.path.join(ROOT, "tests", "data", "catalog", "GRCh38", "FLT3-ITD_exons_13-15.fa")
     fix_db = os.path.join(ROOT, "tests", "data", "jf", "03H116_ITD.jf")
-    if rank == 0 and os.path.exists(fix_fa) and os.path.exists(fix_db):
+    if rank == 0 and os.path.exists(fix_fa) and os.path.exists(fix_db) and not args.only_step:
         from km_amd.cli import read_target
         from km_amd.finder import BatchFinder as _BF
         from km_amd.jellyfish import Jellyfish as _JF
