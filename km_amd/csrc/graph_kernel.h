@@ -144,12 +144,24 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   __syncthreads();
   uint32_t not_pure = 0;
   uint32_t mincov = 0xFFFFFFFFu;
-  for (uint32_t j = tid; j < n_ref; j += NT) {
-    bool wn;
-    const int s = set_insert_lane(pkeys, hcap, nk[j] >> 2, &wn);
-    if (s < 0 || !wn) not_pure = 1;
-    const uint32_t c = ncnt[j];
-    mincov = c < mincov ? c : mincov;
+  // four independent loads in flight per lane, then the (LDS-atomic) inserts
+  for (uint32_t j0 = tid; j0 < n_ref; j0 += 4 * NT) {
+    uint64_t kk[4];
+    uint32_t cc[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + u * NT;
+      kk[u] = j < n_ref ? nk[j] : 0;
+      cc[u] = j < n_ref ? ncnt[j] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (j0 + u * NT >= n_ref) break;
+      bool wn;
+      const int s = set_insert_lane(pkeys, hcap, kk[u] >> 2, &wn);
+      if (s < 0 || !wn) not_pure = 1;
+      mincov = cc[u] < mincov ? cc[u] : mincov;
+    }
   }
   __syncthreads();
   if (tid == 0 && !not_pure) {
