@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--only-step", action="store_true",
                     help="skip the side measurements (end-to-end host path, probe kernels, one-target "
                          "latency): every launch in a profile of this run is a 10 000-target launch")
+    ap.add_argument("--no-ingest", dest="ingest", action="store_false",
+                    help="skip the .jf ingestion measurement (writes a 1.2 GB file to the temp dir)")
     ap.add_argument("--cache", default="", help="directory to keep the generated workload in "
                     "(re-used by later invocations with the same sizes)")
     ap.add_argument("--inflight", type=int, default=4,
@@ -268,6 +270,30 @@ def main():
         e2e = {"targets": n_e, "rows": n_rows, "seconds": time.perf_counter() - t_e}
         e2e["targets_per_s"] = n_e / e2e["seconds"]
 
+    # ---- `.jf` ingestion: the same records as a real binary/sorted file, host
+    #      reader + upload against the direct file -> HBM path
+    ingest = None
+    if rank == 0 and not args.only_step and args.ingest:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "bench.jf")
+            synth.write_jf(path, case["keys"], case["counts"], K)
+            size = os.path.getsize(path)
+            kmlib.Database.load(path, local_rank).close()          # page cache + first-touch warm-up
+            t_i = time.perf_counter()
+            d1 = kmlib.Database.open(path)
+            t_parse = time.perf_counter() - t_i
+            d1.upload(local_rank)
+            t_host = time.perf_counter() - t_i
+            d1.close()
+            t_i = time.perf_counter()
+            d2 = kmlib.Database.load(path, local_rank)
+            t_direct = time.perf_counter() - t_i
+            d2.close()
+        ingest = {"file_bytes": size, "records": int(len(case["keys"])),
+                  "host_reader_parse_s": t_parse, "host_reader_plus_upload_s": t_host,
+                  "direct_file_to_table_s": t_direct, "direct_GBs": size / t_direct / 1e9}
+
     # ---- probe kernels alone (rows A2 / A3): Jellyfish.query and get_child for a resident
     #      array of stored k-mers in random order; 12 resp. 48 algorithmic bytes per element
     probe = None
@@ -381,6 +407,7 @@ def main():
             "single_target_latency": single,
             "probe_kernels": probe,
             "setup_s": {"generate": t_gen, "h2d_broadcast": t_bcast, "table_build": t_build},
+            "jf_ingestion": ingest,
             "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,

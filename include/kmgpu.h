@@ -133,6 +133,11 @@ int kmjf_info(const kmjf_t* h, kmjf_info_t* info);
 /* Borrow the host record arrays (valid until kmjf_close). */
 int kmjf_records(const kmjf_t* h, const uint64_t** keys, const uint32_t** counts, uint64_t* n);
 
+/* Open + upload in one go, without a host copy of the records: the record area of the
+ * memory-mapped file is copied to HBM as it is, unpacked and inserted there (the path for
+ * sample-after-sample runs, example/run_leucegene.sh:29-35).  kmjf_records() then reports none. */
+int kmjf_load(const char* path, int device, kmjf_t** out);
+
 /* Build the HBM-resident table on `device` from the host records. */
 int kmjf_upload(kmjf_t* h, int device);
 /* Build the table from record arrays that already sit in device memory

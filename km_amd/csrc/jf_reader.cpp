@@ -69,7 +69,8 @@ struct Cursor {
 
 }  // namespace
 
-int read_file(const char* path, Records* out, std::string* err) {
+int read_layout(const char* path, Layout* lay, void** file, std::string* err) {
+  *file = nullptr;
   FILE* f = fopen(path, "rb");
   if (!f) { *err = std::string("cannot open ") + path; return 1; }
   char digits[10] = {0};
@@ -118,33 +119,64 @@ int read_file(const char* path, Records* out, std::string* err) {
   if (fseek(f, 0, SEEK_END) != 0) { fclose(f); *err = "seek failed"; return 1; }
   long fsz = ftell(f);
   size_t body = (size_t)fsz - 9 - hlen;
-  size_t n = body / rec;
   fseek(f, (long)(9 + hlen), SEEK_SET);
+  lay->k = (int)(key_len / 2);
+  lay->canonical = canonical;
+  lay->key_bytes = (uint32_t)kb;
+  lay->counter_bytes = (uint32_t)cb;
+  lay->n_records = body / rec;
+  lay->body_offset = 9 + hlen;
+  *file = f;
+  return 0;
+}
 
-  out->k = (int)(key_len / 2);
-  out->canonical = canonical;
-  out->keys.clear();
-  out->counts.clear();
-  out->keys.reserve(n);
-  out->counts.reserve(n);
+int read_file(const char* path, Records* out, std::string* err) {
+  Layout lay;
+  void* file = nullptr;
+  int rc = read_layout(path, &lay, &file, err);
+  if (rc != 0) return rc;
+  FILE* f = static_cast<FILE*>(file);
+  const size_t kb = lay.key_bytes, cb = lay.counter_bytes, rec = kb + cb;
+  const size_t n = (size_t)lay.n_records;
+  out->k = lay.k;
+  out->canonical = lay.canonical;
+  out->keys.resize(n);
+  out->counts.resize(n);
   const size_t CH = 1 << 16;
   std::vector<unsigned char> buf(CH * rec);
-  size_t done = 0;
+  size_t done = 0, kept = 0;
+  uint64_t* keys = out->keys.data();
+  uint32_t* counts = out->counts.data();
   while (done < n) {
     size_t m = (n - done < CH) ? n - done : CH;
     if (fread(buf.data(), rec, m, f) != m) { fclose(f); *err = "truncated record block"; return 1; }
-    for (size_t i = 0; i < m; ++i) {
-      const unsigned char* r = buf.data() + i * rec;
-      uint64_t key = 0;
-      for (size_t b = 0; b < kb; ++b) key |= (uint64_t)r[b] << (8 * b);
-      uint32_t cnt = 0;
-      for (size_t b = 0; b < cb; ++b) cnt |= (uint32_t)r[kb + b] << (8 * b);
-      if (cnt == 0) continue;  // query() returns 0 for absent k-mers anyway
-      out->keys.push_back(key);
-      out->counts.push_back(cnt);
+    if (kb == 8 && cb == 4) {                 // k in 29..32 with 4-byte counters: the common layout
+      for (size_t i = 0; i < m; ++i) {
+        uint64_t key;
+        uint32_t cnt;
+        memcpy(&key, buf.data() + i * 12, 8);
+        memcpy(&cnt, buf.data() + i * 12 + 8, 4);
+        keys[kept] = key;
+        counts[kept] = cnt;
+        kept += cnt != 0;                     // query() returns 0 for absent k-mers anyway
+      }
+    } else {
+      for (size_t i = 0; i < m; ++i) {
+        const unsigned char* r = buf.data() + i * rec;
+        uint64_t key = 0;
+        for (size_t b = 0; b < kb; ++b) key |= (uint64_t)r[b] << (8 * b);
+        uint32_t cnt = 0;
+        for (size_t b = 0; b < cb; ++b) cnt |= (uint32_t)r[kb + b] << (8 * b);
+        if (cnt == 0) continue;
+        keys[kept] = key;
+        counts[kept] = cnt;
+        ++kept;
+      }
     }
     done += m;
   }
+  out->keys.resize(kept);
+  out->counts.resize(kept);
   fclose(f);
   return 0;
 }

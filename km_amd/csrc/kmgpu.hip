@@ -1,6 +1,7 @@
 // kmgpu.hip — libkmgpu.so: C-ABI (include/kmgpu.h) over the HIP kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -384,6 +385,89 @@ extern "C" int kmjf_upload(kmjf_t* h, int device) {
   if (d_keys) (void)hipFree(d_keys);
   if (d_counts) (void)hipFree(d_counts);
   return rc;
+}
+
+// Direct ingestion: header parsed on the host, the record area of the (memory-mapped) file is
+// copied to HBM as it is, unpacked there (k_unpack_records) and the table is built from the
+// device-resident records.  No host copy of the records is made or kept (kmjf_records()
+// reports none).  Measured (bench.py `jf_ingestion`) against the host reader + upload.
+extern "C" int kmjf_load(const char* path, int device, kmjf_t** out) {
+  if (!path || !out) return fail(KM_E_ARG, "null argument");
+  jfio::Layout lay;
+  std::string err;
+  void* file = nullptr;
+  int rc = jfio::read_layout(path, &lay, &file, &err);
+  if (rc == 1) return fail(KM_E_IO, "%s", err.c_str());
+  if (rc == 2) return fail(KM_E_FORMAT, "%s", err.c_str());
+  if (rc == 3) return fail(KM_E_K, "%s", err.c_str());
+  FILE* f = static_cast<FILE*>(file);
+  if (lay.k < 2 || lay.k > 32) { fclose(f); return fail(KM_E_K, "k=%d unsupported", lay.k); }
+  const uint64_t n = lay.n_records;
+  const uint64_t rec = (uint64_t)lay.key_bytes + lay.counter_bytes;
+  const uint64_t body = n * rec;
+  // map the whole file (the record area does not start on a page boundary)
+  const uint64_t map_len = lay.body_offset + body;
+  void* map = nullptr;
+  if (body) {
+    map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+    if (map == MAP_FAILED) { fclose(f); return fail(KM_E_IO, "cannot map %s", path); }
+    (void)madvise(map, map_len, MADV_SEQUENTIAL);
+  }
+  fclose(f);                                   // the mapping stays valid
+  kmjf* h = new (std::nothrow) kmjf;
+  if (!h) { if (map) munmap(map, map_len); return fail(KM_E_NOMEM, "host allocation failed"); }
+  h->k = lay.k;
+  h->canonical = lay.canonical;
+
+  unsigned char* d_raw = nullptr;
+  uint64_t* d_keys = nullptr;
+  uint32_t* d_counts = nullptr;
+  unsigned long long* d_meta = nullptr;
+  auto cleanup = [&]() {
+    if (map) munmap(map, map_len);
+    if (d_raw) (void)hipFree(d_raw);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_meta) (void)hipFree(d_meta);
+  };
+  auto bail = [&](int code, const char* what, hipError_t e) {
+    cleanup();
+    delete h;
+    return fail(code, "%s: %s", what, hipGetErrorString(e));
+  };
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return bail(KM_E_HIP, "device setup failed", e);
+  // KM_LOAD_CHUNK_KB: copy granularity (default 256 MB; tests use small chunks)
+  uint64_t chunk_target = 256ull << 20;
+  if (const char* ck = getenv("KM_LOAD_CHUNK_KB")) { long v = atol(ck); if (v >= 1) chunk_target = (uint64_t)v << 10; }
+  const uint64_t chunk_recs = std::max<uint64_t>(1, chunk_target / rec);
+  if (n) {
+    e = hipMalloc((void**)&d_raw, std::min(n, chunk_recs) * rec);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_keys, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_counts, n * 4);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&d_meta, 8);
+  if (e != hipSuccess) return bail(KM_E_NOMEM, "allocation failed", e);
+  (void)hipMemset(d_meta, 0, 8);
+  const unsigned char* src = static_cast<const unsigned char*>(map) + lay.body_offset;
+  for (uint64_t done = 0; done < n;) {
+    const uint64_t m = std::min(chunk_recs, n - done);
+    e = hipMemcpy(d_raw, src + done * rec, m * rec, hipMemcpyHostToDevice);   // pageable: staged by the runtime
+    if (e != hipSuccess) return bail(KM_E_HIP, "ingestion failed", e);
+    hipLaunchKernelGGL(k_unpack_records, dim3(grid_for(m, 256)), dim3(256), 0, nullptr, d_raw, m, lay.key_bytes,
+                       lay.counter_bytes, d_keys + done, d_counts + done, d_meta);
+    done += m;
+  }
+  unsigned long long nz = 0;
+  e = hipMemcpy(&nz, d_meta, 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return bail(KM_E_HIP, "ingestion failed", e);
+  if (d_raw) { (void)hipFree(d_raw); d_raw = nullptr; }
+  rc = kmjf_upload_from_device(h, device, d_keys, d_counts, n, nullptr);
+  cleanup();
+  if (rc != KM_OK) { delete h; return rc; }
+  h->n_records = nz;
+  *out = h;
+  return KM_OK;
 }
 
 // -------------------------------------------------------------------------- lookups

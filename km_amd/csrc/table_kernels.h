@@ -23,6 +23,32 @@ __global__ void k_count_big(const uint32_t* counts, uint64_t n, unsigned long lo
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
+// Raw `binary/sorted` records as they sit in the file ([kb little-endian key bytes][cb count
+// bytes], kb + cb <= 12) -> key / count arrays.  meta[0] += records with a non-zero count.
+__global__ void k_unpack_records(const unsigned char* raw, uint64_t n, uint32_t kb, uint32_t cb,
+                                 uint64_t* keys, uint32_t* counts, unsigned long long* meta) {
+  unsigned long long nz = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t key = 0;
+    uint32_t cnt = 0;
+    if (kb == 8 && cb == 4) {                 // 12-byte records: three aligned dwords
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(raw) + 3 * i;
+      key = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+      cnt = w[2];
+    } else {
+      const unsigned char* r = raw + i * (kb + cb);
+      for (uint32_t b = 0; b < kb; ++b) key |= (uint64_t)r[b] << (8 * b);
+      for (uint32_t b = 0; b < cb; ++b) cnt |= (uint32_t)r[kb + b] << (8 * b);
+    }
+    keys[i] = key;
+    counts[i] = cnt;
+    nz += cnt != 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o);
+  if ((threadIdx.x & 63) == 0 && nz) atomicAdd(meta, nz);
+}
+
 // Orientations under which a stored record is entered: 0 (a non-canonical key in a canonical
 // database is unreachable by query(), as in the reference), 1 (palindrome / non-canonical
 // database) or 2.

@@ -33,7 +33,8 @@ class Jellyfish:
         self.cutoff = cutoff
         self.n_cutoff = n_cutoff
         self.device = default_device() if device is None else int(device)
-        self.db = db if db is not None else _lib.Database.open(filename)
+        # file -> HBM directly (no host copy of the records); a caller-provided db is used as is
+        self.db = db if db is not None else _lib.Database.load(filename, self.device)
         info = self.db.info
         if info.n_slots == 0:
             self.db.upload(self.device)

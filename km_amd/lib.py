@@ -19,7 +19,7 @@ T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 
 # every symbol include/kmgpu.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "kmjf_open", "kmjf_from_records", "kmjf_create", "kmjf_close", "kmjf_info", "kmjf_records",
+    "kmjf_open", "kmjf_load", "kmjf_from_records", "kmjf_create", "kmjf_close", "kmjf_info", "kmjf_records",
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
@@ -79,6 +79,7 @@ def load():
     u32, u64, i32, i64, dbl = C.c_uint32, C.c_uint64, C.c_int, C.c_int64, C.c_double
     sig = {
         "kmjf_open": [cp, C.POINTER(vp)],
+        "kmjf_load": [cp, i32, C.POINTER(vp)],
         "kmjf_from_records": [vp, vp, u64, i32, i32, C.POINTER(vp)],
         "kmjf_create": [i32, i32, C.POINTER(vp)],
         "kmjf_close": [vp],
@@ -159,6 +160,14 @@ class Database:
         lib = load()
         h = C.c_void_p()
         check(lib.kmjf_open(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path, device=0):
+        """Open + upload without a host copy of the records (direct file -> HBM ingestion)."""
+        lib = load()
+        h = C.c_void_p()
+        check(lib.kmjf_load(os.fsencode(path), int(device), C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -79,6 +79,33 @@ def test_query_every_record_and_absent_keys():
         assert (jf.query_many(absent) == want).all()
 
 
+def test_direct_ingestion_matches_host_reader(tmp_path, monkeypatch):
+    """kmjf_load (file -> pinned buffers -> HBM -> unpack kernel -> table) against the host
+    reader + upload, on a bundled fixture and on a synthetic file with other record widths."""
+    for name in DBS[:2]:
+        d = jr.read_jf("./data/jf/" + name)
+        direct = kmlib.Database.load("./data/jf/" + name, 0)
+        hosted = kmlib.Database.open("./data/jf/" + name).upload(0)
+        a, b = direct.info, hosted.info
+        assert (a.k, a.canonical, a.n_records, a.n_groups, a.n_slots) == (b.k, b.canonical, b.n_records, b.n_groups, b.n_slots)
+        assert (direct.query(d["keys"]) == d["counts"]).all()
+        keys, counts = direct.records()
+        assert len(keys) == 0 and len(counts) == 0            # no host copy is kept
+    rng = np.random.default_rng(3)
+    monkeypatch.setenv("KM_LOAD_CHUNK_KB", "16")               # many chunks through the two pinned buffers
+    for k, n in ((21, 70_000), (31, 300_000)):                 # 6+4 and 8+4 byte records
+        keys = np.unique(rng.integers(0, 1 << (2 * k), size=n, dtype=np.uint64))
+        keys = np.unique(np.array([jr.canonical(int(x), k) for x in keys[:20000]], dtype=np.uint64))
+        counts = rng.integers(1, 5000, size=len(keys)).astype(np.uint32)
+        path = str(tmp_path / ("k%d.jf" % k))
+        synth.write_jf(path, keys, counts, k)
+        direct = kmlib.Database.load(path, 0)
+        assert direct.info.k == k and direct.info.n_records == len(keys)
+        assert (direct.query(keys) == counts).all()
+    with pytest.raises(kmlib.KmError):
+        kmlib.Database.load(str(tmp_path / "missing.jf"), 0)
+
+
 def test_get_child_golden_vectors():
     for case in _load("fixtures_children.json")["cases"]:
         jf = Jellyfish(case["db"], cutoff=case["ratio"], n_cutoff=case["count"])
