@@ -280,16 +280,22 @@ def main():
             synth.write_jf(path, case["keys"], case["counts"], K)
             size = os.path.getsize(path)
             kmlib.Database.load(path, local_rank).close()          # page cache + first-touch warm-up
-            t_i = time.perf_counter()
-            d1 = kmlib.Database.open(path)
-            t_parse = time.perf_counter() - t_i
-            d1.upload(local_rank)
-            t_host = time.perf_counter() - t_i
-            d1.close()
-            t_i = time.perf_counter()
-            d2 = kmlib.Database.load(path, local_rank)
-            t_direct = time.perf_counter() - t_i
-            d2.close()
+            t_parse = t_host = float("inf")
+            for _ in range(3):
+                t_i = time.perf_counter()
+                d1 = kmlib.Database.open(path)
+                t_p = time.perf_counter() - t_i
+                d1.upload(local_rank)
+                t_h = time.perf_counter() - t_i
+                d1.close()
+                if t_h < t_host:
+                    t_parse, t_host = t_p, t_h
+            t_direct = float("inf")
+            for _ in range(3):                                      # best of 3: page-cache state varies
+                t_i = time.perf_counter()
+                d2 = kmlib.Database.load(path, local_rank)
+                t_direct = min(t_direct, time.perf_counter() - t_i)
+                d2.close()
         ingest = {"file_bytes": size, "records": int(len(case["keys"])),
                   "host_reader_parse_s": t_parse, "host_reader_plus_upload_s": t_host,
                   "direct_file_to_table_s": t_direct, "direct_GBs": size / t_direct / 1e9}

@@ -409,7 +409,7 @@ extern "C" int kmjf_load(const char* path, int device, kmjf_t** out) {
   const uint64_t map_len = lay.body_offset + body;
   void* map = nullptr;
   if (body) {
-    map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+    map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fileno(f), 0);   // populate: no per-page faults during the copy
     if (map == MAP_FAILED) { fclose(f); return fail(KM_E_IO, "cannot map %s", path); }
     (void)madvise(map, map_len, MADV_SEQUENTIAL);
   }
