@@ -193,6 +193,31 @@ int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
  * [3] the k_seed kernel alone. */
 int km_batch_timings(km_batch_t* b, float* ms4);
 
+/* ---- host reporting: replaces, for all targets of a fetched batch at once, the per-target
+ *      tail of km/tools/find_mutation.py:53-58 — MutationFinder.graph_analysis' naming and
+ *      quantification (km/utils/MutationFinder.py:190-373, 405-488, 575-833), PathQuant
+ *      (km/utils/PathQuant.py:37-49, 93-154) and the row order.  Pure host code. */
+typedef struct {
+  uint32_t n_targets;
+  const uint8_t* bases;          /* target sequences as given (ASCII), concatenated           */
+  const uint64_t* base_off;      /* [n_targets+1]                                             */
+  const char* const* names;      /* [n_targets] NUL-terminated query names                    */
+  const char* db_name;           /* the Database column                                       */
+  int32_t k;
+  int32_t reserved;
+  const km_batch_out_t* res;     /* arrays filled by km_batch_fetch (all of them)             */
+} km_report_in_t;
+/* text: the TSV rows of every KM_T_OK target, rows of one target separated by '\n';
+ * row_off[t] .. row_off[t+1] is the block of target t (empty for other statuses);
+ * err[t] != 0 where the reference would have raised while naming a variant
+ * (1 IndexError, 2 "mutation identification could be incorrect", 3 AssertionError,
+ * 4 ValueError; no rows then), or 100 = rows delivered, but a printed rVAF / expression sits
+ * within 1e-6 of a %.3f / %.1f rounding tie, where the last bits of the least-squares solver
+ * decide the digit: a caller that needs the reference's exact text recomputes that target with
+ * numpy (km_amd.lib.report_rows does).  Release the three arrays with km_report_free. */
+int km_report_rows(const km_report_in_t* in, char** text, uint64_t** row_off, int32_t** err);
+void km_report_free(char* text, uint64_t* row_off, int32_t* err);
+
 /* Diagnostics: with KM_SEED_STAMPS set in the environment k_seed records, per wave, eight
  * s_memtime stamps (start, header, bases, minimizer scan, directory words, slots, resolved,
  * end), two s_memrealtime stamps (start, end) and the HW_ID placement, 16 words per wave.

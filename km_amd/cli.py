@@ -66,11 +66,13 @@ def main_find_mut(args, out=sys.stdout):
         name = os.path.splitext(os.path.basename(f))[0]
         targets.append((name, read_target(f)))
     finder = BatchFinder(jf, args.steps, args.branchs, args.nodes)
-    for res in finder.analyse(targets):
-        if isinstance(res, NodeLimitExceeded):
+    for rows in finder.rows(targets):              # native reporting (km_report_rows)
+        if isinstance(rows, NodeLimitExceeded):
             out.flush()
-            sys.exit(str(res))
-        for row in report.target_rows(res, jf.filename):
+            sys.exit(str(rows))
+        if isinstance(rows, BaseException):        # what the reference raises while naming a variant
+            raise rows
+        for row in rows:
             out.write(row + "\n")
     out.write("#Elapsed time:" + str(time.time() - t0) + "\n")
 

@@ -55,15 +55,10 @@ class BatchFinder:
         b.run(stream=stream)
         return b.fetch()
 
-    def analyse(self, targets):
-        """targets: list of (name, seq).  Returns a list with one TargetResult per
-        target, or the exception the reference would have raised at that target."""
-        names = [t[0] for t in targets]
-        seqs = [t[1] for t in targets]
-        k = self.jf.k
-        raw = self.run_raw(seqs)
+    def _raise_input_errors(self, raw, names, seqs):
         # RefSeq construction comes first for every target in the reference
         # (km/tools/find_mutation.py:37-45): its errors pre-empt all output
+        k = self.jf.k
         for t, st in enumerate(raw["status"].tolist()):
             if st == _lib.T_EMPTY:
                 raise AssertionError("target %s is shorter than k=%d" % (names[t], k))
@@ -73,6 +68,29 @@ class BatchFinder:
                 raise ValueError(repeated_kmer_message(seqs[t], names[t], k))
             if st == _lib.T_INTERNAL:
                 raise RuntimeError("libkmgpu: internal workspace overflow on target %s" % names[t])
+
+    def rows(self, targets, db_name=None):
+        """targets: list of (name, seq).  The TSV rows of every target through the native
+        reporting path (km_report_rows): a list with, per target, the list of its row strings
+        or the exception the reference would have raised at that target."""
+        names = [t[0] for t in targets]
+        seqs = [t[1] for t in targets]
+        raw = self.run_raw(seqs)
+        self._raise_input_errors(raw, names, seqs)
+        out = _lib.report_rows(raw, names, seqs, self.jf.k, self.jf.filename if db_name is None else db_name)
+        for t, st in enumerate(raw["status"].tolist()):
+            if st == _lib.T_NODE_LIMIT:
+                out[t] = NodeLimitExceeded(self.max_node)
+        return out
+
+    def analyse(self, targets):
+        """targets: list of (name, seq).  Returns a list with one TargetResult per
+        target, or the exception the reference would have raised at that target."""
+        names = [t[0] for t in targets]
+        seqs = [t[1] for t in targets]
+        k = self.jf.k
+        raw = self.run_raw(seqs)
+        self._raise_input_errors(raw, names, seqs)
         out = []
         noff = raw["node_off"]
         poff = raw["path_off"]

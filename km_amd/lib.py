@@ -23,7 +23,8 @@ SYMBOLS = [
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
-    "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_batch_debug_stamps", "km_strerror", "km_last_error",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_batch_debug_stamps",
+    "km_report_rows", "km_report_free", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
 
@@ -61,6 +62,13 @@ class BatchOut(C.Structure):
                 ("node_off", _P64), ("node_kmer", _P64), ("node_count", _P32),
                 ("path_off", _P32), ("run_off", _P64), ("run_start", _P32), ("run_len", _P32),
                 ("path_len", _P32), ("path_min_cov", _P32)]
+
+
+class ReportIn(C.Structure):
+    """km_report_in_t (include/kmgpu.h)."""
+    _fields_ = [("n_targets", C.c_uint32), ("bases", C.c_void_p), ("base_off", C.c_void_p),
+                ("names", C.POINTER(C.c_char_p)), ("db_name", C.c_char_p), ("k", C.c_int32),
+                ("reserved", C.c_int32), ("res", C.POINTER(BatchOut))]
 
 
 _lib = None
@@ -101,6 +109,8 @@ def load():
         "km_batch_fetch": [vp, C.POINTER(BatchOut)],
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
         "km_batch_debug_stamps": [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)],
+        "km_report_rows": [C.POINTER(ReportIn), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
+                           C.POINTER(C.POINTER(C.c_int32))],
         "km_device_count": [C.POINTER(i32)],
         "km_stream_create": [i32, C.POINTER(vp)],
         "km_stream_destroy": [vp],
@@ -112,6 +122,8 @@ def load():
     for name in ("km_strerror", "km_last_error", "km_version"):
         getattr(lib, name).restype = cp
     lib.km_strerror.argtypes = [i32]
+    lib.km_report_free.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    lib.km_report_free.restype = None
     _lib = lib
     return lib
 
@@ -376,3 +388,75 @@ def expand_path(res, p):
     return np.concatenate([np.arange(s, s + l, dtype=np.int64)
                            for s, l in zip(res["run_start"][a:b].tolist(),
                                            res["run_len"][a:b].tolist())])
+
+
+REPORT_ERRORS = {1: IndexError("list index out of range"),
+                 2: Exception("mutation identification could be incorrect"),
+                 3: AssertionError(), 4: ValueError("min() arg is an empty sequence")}
+
+
+def _python_rows(res, t, name, seq, k, db_name):
+    """Rows of target t through the Python restatement (km_amd/report.py)."""
+    from . import report
+    a, e = int(res["node_off"][t]), int(res["node_off"][t + 1])
+    p0, p1 = int(res["path_off"][t]), int(res["path_off"][t + 1])
+    paths = [expand_path(res, p) for p in range(p0, p1)]
+    seq = seq if isinstance(seq, str) else bytes(seq).decode("ascii")
+    tr = report.TargetResult(name, seq, k, int(res["n_ref"][t]), np.asarray(res["node_kmer"][a:e]),
+                             np.asarray(res["node_count"][a:e]), paths,
+                             np.asarray(res["path_min_cov"][p0:p1]).tolist())
+    return report.target_rows(tr, db_name)
+
+
+def report_rows(res, names, seqs, k, db_name):
+    """TSV rows of every target of a fetched batch (dict from Batch.fetch) through the C++
+    reporting path: returns a list with, per target, a list of row strings (empty unless the
+    target's status is KM_T_OK) or the exception the reference would have raised."""
+    lib = load()
+    n = len(names)
+    enc = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(e) for e in enc], out=offs[1:])
+    blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+    out = BatchOut()
+    keep = []
+    for field, ctype in (("status", C.c_uint32), ("n_ref", C.c_uint32), ("probes", C.c_uint64),
+                         ("node_off", C.c_uint64), ("node_kmer", C.c_uint64), ("node_count", C.c_uint32),
+                         ("path_off", C.c_uint32), ("run_off", C.c_uint64), ("run_start", C.c_uint32),
+                         ("run_len", C.c_uint32), ("path_len", C.c_uint32), ("path_min_cov", C.c_uint32)):
+        arr = np.ascontiguousarray(res[field], dtype=np.dtype(ctype))
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=arr.dtype)
+        keep.append(arr)
+        setattr(out, field, typed_ptr(arr, ctype))
+    inp = ReportIn()
+    inp.n_targets = n
+    inp.bases = blob.ctypes.data
+    inp.base_off = offs.ctypes.data
+    name_arr = (C.c_char_p * max(1, n))(*[nm.encode() for nm in names])
+    inp.names = name_arr
+    inp.db_name = str(db_name).encode()
+    inp.k = int(k)
+    inp.res = C.pointer(out)
+    text = C.c_void_p()
+    row_off = C.POINTER(C.c_uint64)()
+    err = C.POINTER(C.c_int32)()
+    check(lib.km_report_rows(C.byref(inp), C.byref(text), C.byref(row_off), C.byref(err)))
+    try:
+        total = int(row_off[n])
+        blob_out = C.string_at(text, total).decode("ascii")
+        result = []
+        for t in range(n):
+            if err[t] == 100:
+                # a printed value sits on a %.1f / %.3f rounding tie: the digit depends on the
+                # last bits of the least-squares solver — recompute with numpy, like the reference
+                result.append(_python_rows(res, t, names[t], seqs[t], k, db_name))
+                continue
+            if err[t]:
+                result.append(REPORT_ERRORS.get(int(err[t]), RuntimeError("report error %d" % err[t])))
+                continue
+            a, e = int(row_off[t]), int(row_off[t + 1])
+            result.append(blob_out[a:e].split("\n") if e > a else [])
+    finally:
+        lib.km_report_free(text, row_off, err)
+    return result

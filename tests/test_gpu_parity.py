@@ -528,3 +528,17 @@ def test_randomized_parameter_sweep_against_c_oracle():
         b.close()
         db.close()
     assert n_cases > 300 and n_limit > 5 and n_multi > 25, (n_cases, n_limit, n_multi)
+
+
+def test_native_reporting_equals_python_reporting_on_a_gpu_batch():
+    """BatchFinder.rows (km_report_rows over the fetched arrays) against BatchFinder.analyse +
+    km_amd/report.py, 600 synthetic targets."""
+    case = synth.make_case(n_targets=600, length=400, n_keys=300_000, seed=31337, variant_frac=0.5)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    finder = BatchFinder(jf)
+    targets = [(n, km.decode(r)) for n, r in zip(case["names"], case["targets"])]
+    native = finder.rows(targets)
+    python = [report.target_rows(res, jf.filename) for res in finder.analyse(targets)]
+    assert native == python
+    assert sum(len(r) > 1 for r in native) > 150

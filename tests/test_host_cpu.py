@@ -92,7 +92,7 @@ def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports every entry point of include/kmgpu.h."""
     lib = kmlib.load()
     hdr = open(os.path.join(ROOT, "include", "kmgpu.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(km\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(km\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(kmlib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name

@@ -1,0 +1,147 @@
+"""CPU-only parity tests of the native reporting path (km_report_rows, csrc/report.cpp)
+against the reference's golden TSVs and against the Python restatement km_amd/report.py.
+The oracle only produces the hot path's outputs here (on a GPU box they come from the HIP
+kernels); it is the checker's input, not the thing under test."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from km_amd import kmer as km
+from km_amd import lib as kmlib
+from km_amd import report, synth
+from oracle import km_oracle as ko
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(autouse=True)
+def _cwd(monkeypatch):
+    monkeypatch.chdir(HERE)
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as fh:
+        return json.load(fh)
+
+
+def _raw_from_oracle(results):
+    """The dict Batch.fetch() returns, rebuilt from oracle outputs (paths run-length encoded
+    like the kernels deliver them)."""
+    status, n_ref, probes, node_off = [], [], [], [0]
+    node_kmer, node_count = [], []
+    path_off, run_off, run_start, run_len, path_len, path_min_cov = [0], [0], [], [], [], []
+    for res in results:
+        status.append(0)
+        n_ref.append(res["n_ref"])
+        probes.append(res["probes"])
+        node_kmer += [km.pack_str(s) for s in res["kmers"]]
+        node_count += list(res["counts"])
+        node_off.append(len(node_kmer))
+        for p, mc in zip(res["paths"], res["min_cov"]):
+            p = list(p)
+            i = 0
+            while i < len(p):
+                j = i
+                while j + 1 < len(p) and p[j + 1] == p[j] + 1:
+                    j += 1
+                run_start.append(p[i])
+                run_len.append(j - i + 1)
+                i = j + 1
+            run_off.append(len(run_start))
+            path_len.append(len(p))
+            path_min_cov.append(mc)
+        path_off.append(len(path_len))
+    u32, u64 = np.uint32, np.uint64
+    return {"status": np.array(status, u32), "n_ref": np.array(n_ref, u32), "probes": np.array(probes, u64),
+            "node_off": np.array(node_off, u64), "node_kmer": np.array(node_kmer, u64),
+            "node_count": np.array(node_count, u32), "path_off": np.array(path_off, u32),
+            "run_off": np.array(run_off, u64), "run_start": np.array(run_start, u32),
+            "run_len": np.array(run_len, u32), "path_len": np.array(path_len, u32),
+            "path_min_cov": np.array(path_min_cov, u32)}
+
+
+def _python_rows(res, seq, db_name):
+    kmers = np.array([km.pack_str(s) for s in res["kmers"]], dtype=np.uint64)
+    tr = report.TargetResult(res["name"], seq, res["k"], res["n_ref"], kmers,
+                             np.array(res["counts"], dtype=np.uint32),
+                             [np.array(p, dtype=np.int64) for p in res["paths"]], res["min_cov"])
+    return report.target_rows(tr, db_name)
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_native_rows_match_reference_golden_tsv(idx):
+    case = _load("fixtures_tsv.json")["cases"][idx]
+    db = ko.KmerDB(case["db"], cutoff=0.05, n_cutoff=5)
+    results, names, seqs = [], [], []
+    for fa in case["targets"]:
+        seq = ko.read_fasta_concat(fa)
+        name = os.path.splitext(os.path.basename(fa))[0]
+        results.append(ko.analyse_target(seq, name, db))
+        names.append(name)
+        seqs.append(seq)
+    blocks = kmlib.report_rows(_raw_from_oracle(results), names, seqs, 31, case["db"])
+    rows = [r for b in blocks for r in b]
+    assert [report.HEADER] + rows == case["lines"][10:]
+
+
+@pytest.mark.parametrize("name", [s["name"] for s in synth.GOLDEN_SPECS])
+def test_native_rows_match_python_restatement(name, tmp_path):
+    spec = [s for s in synth.GOLDEN_SPECS if s["name"] == name]
+    fas, dbp, _ = synth.write_case(str(tmp_path), **spec[0])
+    db = ko.KmerDB(dbp, cutoff=0.05, n_cutoff=5)
+    results, names, seqs = [], [], []
+    for fa in fas[:40]:
+        seq = ko.read_fasta_concat(fa)
+        nm = os.path.splitext(os.path.basename(fa))[0]
+        results.append(ko.analyse_target(seq, nm, db))
+        names.append(nm)
+        seqs.append(seq)
+    blocks = kmlib.report_rows(_raw_from_oracle(results), names, seqs, results[0]["k"], "x.jf")
+    n_var = 0
+    for res, seq, got in zip(results, seqs, blocks):
+        assert got == _python_rows(res, seq, "x.jf")
+        n_var += len(got) > 1
+    assert n_var >= 3 or name in ("budget", "nodelimit")
+
+
+def test_native_rows_skip_non_ok_targets_and_empty_batch():
+    assert kmlib.report_rows({"status": np.zeros(0, np.uint32), "n_ref": np.zeros(0, np.uint32),
+                              "probes": np.zeros(0, np.uint64), "node_off": np.zeros(1, np.uint64),
+                              "node_kmer": np.zeros(0, np.uint64), "node_count": np.zeros(0, np.uint32),
+                              "path_off": np.zeros(1, np.uint32), "run_off": np.zeros(1, np.uint64),
+                              "run_start": np.zeros(0, np.uint32), "run_len": np.zeros(0, np.uint32),
+                              "path_len": np.zeros(0, np.uint32), "path_min_cov": np.zeros(0, np.uint32)},
+                             [], [], 31, "x.jf") == []
+    case = _load("fixtures_tsv.json")["cases"][0]
+    db = ko.KmerDB(case["db"], cutoff=0.05, n_cutoff=5)
+    fa = case["targets"][0]
+    seq = ko.read_fasta_concat(fa)
+    res = ko.analyse_target(seq, "t", db)
+    raw = _raw_from_oracle([res, res])
+    raw["status"][0] = kmlib.T_NODE_LIMIT
+    blocks = kmlib.report_rows(raw, ["a", "b"], [seq, seq], 31, "d.jf")
+    assert blocks[0] == [] and blocks[1] == _python_rows(dict(res, name="b"), seq, "d.jf")
+
+
+def test_native_rows_many_random_variants():
+    """A few hundred synthetic variant targets (all variant kinds, clusters, tandem duplications):
+    every row text of the native path equals the Python restatement's."""
+    case = synth.make_case(n_targets=260, length=300, k=31, n_keys=150_000, seed=4242, variant_frac=0.9,
+                           exact_pad=False)
+    db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                   records={"k": 31, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+    results, names, seqs = [], [], []
+    for i in range(260):
+        seq = km.decode(case["targets"][i])
+        results.append(ko.analyse_target(seq, case["names"][i], db))
+        names.append(case["names"][i])
+        seqs.append(seq)
+    blocks = kmlib.report_rows(_raw_from_oracle(results), names, seqs, 31, "rnd.jf")
+    kinds = set()
+    for res, seq, got in zip(results, seqs, blocks):
+        assert got == _python_rows(res, seq, "rnd.jf")
+        kinds.update(r.split("\t")[2] for r in got)
+    assert {"Reference", "Substitution", "Insertion", "Deletion", "ITD"} <= kinds
