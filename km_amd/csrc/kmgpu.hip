@@ -581,6 +581,9 @@ struct km_batch {
   uint32_t max_len = 0;
   bool ran_walk = false, ran_graph = false, synced = true;
   hipStream_t last_stream = nullptr;
+  // pinned staging for km_batch_fetch (node pools cross PCIe at DMA speed, no zero-filled vectors)
+  unsigned char* pin = nullptr;
+  uint64_t pin_cap = 0;
 
   // inputs
   DevBuf<uint8_t> d_bases;
@@ -741,6 +744,7 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
   b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release(); b->d_stamps.release();
   for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->pin) (void)hipHostFree(b->pin);
   delete b;
   return KM_OK;
 }
@@ -1375,18 +1379,27 @@ extern "C" int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out) {
     }
     if (out->node_off) memcpy(out->node_off, noff.data(), (n + 1) * 8);
     if (out->node_kmer || out->node_count) {
-      // pull the used part of the pools, then compact on the host
-      std::vector<uint64_t> hk(out->node_kmer ? b->node_pool_used : 0);
-      std::vector<uint32_t> hc(out->node_count ? b->node_pool_used : 0);
-      if (out->node_kmer && b->node_pool_used)
-        HIPCHK(hipMemcpy(hk.data(), b->d_node_kmer.p, b->node_pool_used * 8, hipMemcpyDeviceToHost));
-      if (out->node_count && b->node_pool_used)
-        HIPCHK(hipMemcpy(hc.data(), b->d_node_cnt.p, b->node_pool_used * 4, hipMemcpyDeviceToHost));
+      // pull the used part of the pools through a pinned staging buffer, compact on the host
+      const uint64_t used = b->node_pool_used;
+      const uint64_t need = used * 12 + 64;
+      if (need > b->pin_cap) {
+        if (b->pin) (void)hipHostFree(b->pin);
+        b->pin = nullptr;
+        b->pin_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&b->pin, need + need / 4, hipHostMallocDefault));
+        b->pin_cap = need + need / 4;
+      }
+      const uint64_t* hk = reinterpret_cast<const uint64_t*>(b->pin);
+      const uint32_t* hc = reinterpret_cast<const uint32_t*>(b->pin + used * 8);
+      if (out->node_kmer && used)
+        HIPCHK(hipMemcpy(b->pin, b->d_node_kmer.p, used * 8, hipMemcpyDeviceToHost));
+      if (out->node_count && used)
+        HIPCHK(hipMemcpy(b->pin + used * 8, b->d_node_cnt.p, used * 4, hipMemcpyDeviceToHost));
       for (uint32_t t = 0; t < n; ++t) {
         const uint64_t cnt = noff[t + 1] - noff[t];
         if (!cnt) continue;
-        if (out->node_kmer) memcpy(out->node_kmer + noff[t], hk.data() + b->h_node_base[t], cnt * 8);
-        if (out->node_count) memcpy(out->node_count + noff[t], hc.data() + b->h_node_base[t], cnt * 4);
+        if (out->node_kmer) memcpy(out->node_kmer + noff[t], hk + b->h_node_base[t], cnt * 8);
+        if (out->node_count) memcpy(out->node_count + noff[t], hc + b->h_node_base[t], cnt * 4);
       }
     }
   }
