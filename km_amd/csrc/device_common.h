@@ -31,6 +31,10 @@
 //        slots: the (k-1)-mers of one super-k-mer fall into consecutive classes and never
 //        collide with each other, so a lookup finds its slot in the aligned pair it reads
 //        first and the next (k-1)-mer of a walk sits q slots further in the same HBM lines.
+//      * a bucket that still cannot keep its keys in their home pairs after two doublings
+//        (real data: dozens of error variants of one super-k-mer crowd a few classes) becomes
+//        a plain hash table over all its pairs (S = an ODD multiple of NC marks it) and probes
+//        linearly; max_probe bounds every lookup.
 //      A wave waits for its slowest lane: bounding the probe length matters more than its mean.
 //
 // Counts are stored as u16; a count >= 65535 is stored as 0xFFFF and its exact value
@@ -258,6 +262,9 @@ __device__ inline uint32_t pick4(uint4 v, uint32_t i) {
 __device__ inline uint64_t home_slot(const TableView& t, const Key& key, uint64_t S) {
   const uint64_t q = S >> t.cshift;
   if (q) {
+    // odd multiple of NC: a crowded bucket (many near-identical super-k-mers behind one
+    // minimizer pile up in a few classes) — plain hashing over all its pairs
+    if (q & 1) return (uint64_t)__umulhi(key.hsub, (uint32_t)(S >> 1)) << 1;
     // class mode: S = q * NC, q even; the class owns q slots
     return (uint64_t)key.cls * q + (__umulhi(key.hsub, (uint32_t)q) & ~1u);
   }

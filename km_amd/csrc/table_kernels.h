@@ -111,8 +111,11 @@ __global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift) {
     const uint32_t c = caps[i];
     if (!(c & CAP_GROW)) continue;
     const uint32_t gen = cap_gen(c);
-    const uint64_t pairs = shape_capacity(4ull * (c & CAP_SIZE), NC) >> 1;
-    caps[i] = (uint32_t)pairs | ((gen + 1) << CAP_GEN_SHIFT);
+    uint64_t slots = shape_capacity(4ull * (c & CAP_SIZE), NC);
+    // the last doubling of a class-mode bucket turns it into a plain hash table over all its
+    // pairs (an odd multiple of NC, see home_slot): its classes are too unevenly filled
+    if (gen + 1 == CAP_MAX_GEN && slots >= 2 * NC) slots += NC;
+    caps[i] = (uint32_t)(slots >> 1) | ((gen + 1) << CAP_GEN_SHIFT);
   }
 }
 
