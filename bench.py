@@ -408,6 +408,7 @@ def main():
             "gprobes_per_s": world * probes_per_step / (dt / args.steps) / 1e9,
             "logical_probes_per_step": probes_per_step,
             "table_fetches_per_step": fetches_per_step,
+            "targets_in_large_tier": int(sizes.n_big_tier), "targets_flagged": int(sizes.n_flagged),
             "kernel_ms": {"walk": walk_avg, "k_seed": seed_avg, "graph": graph_avg},
             "batches_in_flight": n_fl,
             "hipgraph_replay": bool(args.hipgraph),

@@ -565,7 +565,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-constexpr uint32_t FAST_EXTRA = 192;          // walk-discovered nodes a fast-tier target may add
+constexpr uint32_t FAST_EXTRA = 160;          // walk-discovered nodes a fast-tier target may add
 constexpr uint32_t FAST_LDS_LIMIT = 64 * 1024;
 
 }  // namespace
