@@ -75,9 +75,14 @@ class BatchFinder:
         or the exception the reference would have raised at that target."""
         names = [t[0] for t in targets]
         seqs = [t[1] for t in targets]
-        raw = self.run_raw(seqs)
+        packed = _lib.pack_sequences(seqs)               # encoded once, for the GPU and for the report
+        b = self._ensure(len(seqs), int(packed[1][-1]))
+        b.set_targets_packed(*packed)
+        b.run()
+        raw = b.fetch()
         self._raise_input_errors(raw, names, seqs)
-        out = _lib.report_rows(raw, names, seqs, self.jf.k, self.jf.filename if db_name is None else db_name)
+        out = _lib.report_rows(raw, names, seqs, self.jf.k, self.jf.filename if db_name is None else db_name,
+                               packed=packed)
         for t, st in enumerate(raw["status"].tolist()):
             if st == _lib.T_NODE_LIMIT:
                 out[t] = NodeLimitExceeded(self.max_node)

@@ -292,10 +292,7 @@ class Batch:
 
     def set_targets(self, seqs):
         """seqs: list of str/bytes (ACGT)."""
-        enc = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
-        offs = np.zeros(len(enc) + 1, dtype=np.uint64)
-        np.cumsum([len(e) for e in enc], out=offs[1:])
-        blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+        blob, offs = pack_sequences(seqs)
         self.set_targets_packed(blob, offs)
 
     def set_targets_packed(self, blob, offsets):
@@ -408,16 +405,22 @@ def _python_rows(res, t, name, seq, k, db_name):
     return report.target_rows(tr, db_name)
 
 
-def report_rows(res, names, seqs, k, db_name):
+def pack_sequences(seqs):
+    """(blob, offsets): the sequences as one uint8 array + uint64 offsets[n+1]."""
+    enc = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    np.cumsum([len(e) for e in enc], out=offs[1:])
+    return np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8), offs
+
+
+def report_rows(res, names, seqs, k, db_name, packed=None):
     """TSV rows of every target of a fetched batch (dict from Batch.fetch) through the C++
     reporting path: returns a list with, per target, a list of row strings (empty unless the
-    target's status is KM_T_OK) or the exception the reference would have raised."""
+    target's status is KM_T_OK) or the exception the reference would have raised.
+    `packed` = pack_sequences(seqs) when the caller already has it."""
     lib = load()
     n = len(names)
-    enc = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
-    offs = np.zeros(n + 1, dtype=np.uint64)
-    np.cumsum([len(e) for e in enc], out=offs[1:])
-    blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+    blob, offs = packed if packed is not None else pack_sequences(seqs)
     out = BatchOut()
     keep = []
     for field, ctype in (("status", C.c_uint32), ("n_ref", C.c_uint32), ("probes", C.c_uint64),
