@@ -254,6 +254,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   Slot* slots = nullptr;
   uint64_t slots_cap = 0;
   OvfSlot* ovf = nullptr;
+  uint32_t** ctr_ptr = nullptr;
   auto bail = [&](int code, const char* what, hipError_t e) {
     if (dir) (void)hipFree(dir);
     if (caps) (void)hipFree(caps);
@@ -261,6 +262,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     if (d_meta) (void)hipFree(d_meta);
     if (slots) (void)hipFree(slots);
     if (ovf) (void)hipFree(ovf);
+    if (ctr_ptr && *ctr_ptr) (void)hipFree(*ctr_ptr);
     return fail(code, "%s: %s", what, hipGetErrorString(e));
   };
   hipError_t e = hipMalloc((void**)&dir, dir_words * 4);
@@ -288,7 +290,10 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   unsigned long long meta[6] = {0, 0, 0, 0, 0, 0};
   uint64_t n_slots = 0;
   uint32_t max_probe = 2;
-  int rounds = 0;
+  int rounds = 0, dry_rounds = 0;
+  uint32_t* ctr = nullptr;          // dry rounds: entries per home pair, one byte each
+  uint64_t ctr_cap = 0;
+  ctr_ptr = &ctr;
   for (;; ++rounds) {
     const int final_round = rounds >= MAX_ROUNDS;
     (void)hipMemsetAsync(d_meta, 0, 32, st);          // [0..3]
@@ -304,11 +309,38 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     if (meta[5] >= (1ull << 32))
       return bail(KM_E_CAPACITY, "table needs more than 2^33 slots (32-bit directory)", hipSuccess);
     n_slots = std::max<uint64_t>(64, 2ull * meta[5]);
+    if (n && dry_rounds < (int)CAP_MAX_GEN) {
+      // dry round (cheap: one byte per pair instead of the slots): find the buckets to double
+      const uint64_t words = meta[5] / 4 + 2;
+      if (words > ctr_cap) {
+        if (ctr) (void)hipFree(ctr);
+        ctr = nullptr;
+        ctr_cap = words + words / 2;
+        e = hipMalloc((void**)&ctr, ctr_cap * 4);
+        if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
+      }
+      (void)hipMemsetAsync(ctr, 0, words * 4, st);
+      hipLaunchKernelGGL(k_table_dry, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, d_keys, d_counts, n, caps,
+                         ctr, d_meta);
+      e = hipMemcpyAsync(meta, d_meta, 32, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return bail(KM_E_HIP, "table build failed", e);
+      ++dry_rounds;
+      if (getenv("KM_BUILD_VERBOSE"))
+        fprintf(stderr, "libkmgpu: dry round %d: %llu slots, %llu buckets to grow\n", dry_rounds,
+                (unsigned long long)n_slots, meta[2]);
+      if (meta[2]) {
+        hipLaunchKernelGGL(k_dir_grow, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
+                           (uint64_t)n_buckets, tv.cshift);
+        continue;
+      }
+      dry_rounds = (int)CAP_MAX_GEN;               // nothing to grow: go straight to the insert
+    }
     if (n_slots > slots_cap) {
       if (slots) (void)hipFree(slots);
       slots = nullptr;
       slots_cap = n_slots + n_slots / 4;              // head room for the following rounds
-      e = hipMalloc((void**)&slots, slots_cap * sizeof(Slot));
+      e = hipMalloc((void**)&slots, (slots_cap + 16) * sizeof(Slot));
       if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
     }
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
@@ -350,6 +382,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   (void)hipFree(caps);
   (void)hipFree(sums);
   (void)hipFree(d_meta);
+  if (ctr) (void)hipFree(ctr);
   h->d_slots = slots;
   h->d_dir = dir;
   h->n_buckets = n_buckets;

@@ -229,6 +229,33 @@ __global__ void k_ovf_insert(const uint64_t* keys, const uint32_t* counts, uint6
   }
 }
 
+// Dry round: which buckets would not keep every key in its home pair?  Same key / directory /
+// home computation as the insert, but instead of the 10 GB of slots it touches one byte per
+// pair (entries per home pair, four counters per word).  Conservative: siblings that will share
+// a slot are counted separately.  A bucket whose pair receives a third entry is flagged in
+// caps[] while it may still double (meta[2] counts flagged buckets).
+__global__ void k_table_dry(TableView t, const uint64_t* keys, const uint32_t* counts, uint64_t n,
+                            uint32_t* caps, uint32_t* pair_ctr, unsigned long long* meta) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t K = keys[i];
+    if (counts[i] == 0) continue;
+    uint64_t R;
+    const int n_or = record_orientations(K, t.k, t.canonical, &R);
+    for (int o = 0; o < n_or; ++o) {
+      const Key g = make_key(t, (o ? R : K) >> 2);
+      const uint32_t lo = t.dir[g.bucket], hi = t.dir[g.bucket + 1];
+      const uint64_t S = bucket_slots(lo, hi);
+      if (S == 0) continue;
+      const uint64_t pair = (uint64_t)lo + (home_slot(t, g, S) >> 1);
+      const uint32_t sh = 8u * (uint32_t)(pair & 3);
+      const uint32_t old = atomicAdd(&pair_ctr[pair >> 2], 1u << sh);
+      if (((old >> sh) & 0xFFu) >= 2u && cap_gen(caps[g.bucket]) < CAP_MAX_GEN)
+        if (!(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW)) atomicAdd(&meta[2], 1ull);
+    }
+  }
+}
+
 // Insert pass: one record per thread, entered under the group of each orientation into the
 // home pair of its bucket.  A key whose home pair is taken flags its bucket in caps[]
 // (meta[2] counts flagged buckets) — the host doubles those buckets and rebuilds — unless the
