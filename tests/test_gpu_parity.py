@@ -542,3 +542,29 @@ def test_native_reporting_equals_python_reporting_on_a_gpu_batch():
     python = [report.target_rows(res, jf.filename) for res in finder.analyse(targets)]
     assert native == python
     assert sum(len(r) > 1 for r in native) > 150
+
+
+def test_plain_c_client(tmp_path):
+    """tests/c_abi/find_mutation.c: a gcc-built C program (no Python, no torch in the process)
+    drives the whole boundary — kmjf_load, km_batch_*, km_report_rows — and prints the
+    reference's TSV rows for the single-target golden cases."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "find_mutation_c")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(HERE, "c_abi", "find_mutation.c"), "-L", os.path.join(root, "km_amd"),
+                           "-lkmgpu", "-Wl,-rpath," + os.path.join(root, "km_amd"), "-o", exe])
+    n = 0
+    for case in _load("fixtures_tsv.json")["cases"]:
+        if len(case["targets"]) != 1:
+            continue
+        fa = case["targets"][0]
+        name = os.path.splitext(os.path.basename(fa))[0]
+        res = subprocess.run([exe, fa, case["db"], name], capture_output=True, text=True, cwd=HERE, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert res.stdout.rstrip("\n").split("\n") == case["lines"][11:]
+        n += 1
+    assert n >= 5
