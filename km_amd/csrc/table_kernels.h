@@ -266,6 +266,8 @@ __global__ void k_table_dry(TableView t, const uint64_t* keys, const uint32_t* c
 __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
                                const uint32_t* counts, uint64_t n, uint32_t* caps, int final,
                                unsigned long long* meta) {
+  unsigned long long claimed = 0;          // slots this thread occupied (summed per wave at the end:
+                                           // one same-address atomic per slot would serialise the kernel)
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t K = keys[i];
@@ -288,7 +290,7 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
         if (step == 2 && may_grow) break;               // the pair is taken: grow this bucket
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&base[idx].tag),
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
-        if (old == EMPTY) atomicAdd(&meta[0], 1ull);
+        claimed += old == EMPTY;
         if (old == EMPTY || old == g.tag) {
           base[idx].c[s] = (uint16_t)(v >= COUNT_ESCAPE ? COUNT_ESCAPE : v);
           if (step >= 2) atomicMax(&meta[3], (unsigned long long)step);
@@ -306,6 +308,8 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
       }
     }
   }
+  for (int o = 32; o > 0; o >>= 1) claimed += __shfl_xor(claimed, o);
+  if ((threadIdx.x & 63) == 0 && claimed) atomicAdd(&meta[0], claimed);
 }
 
 // Jellyfish.query for a batch (km/utils/Jellyfish.py:47-53; the loop of
