@@ -236,6 +236,7 @@ __global__ void k_ovf_insert(const uint64_t* keys, const uint32_t* counts, uint6
 // caps[] while it may still double (meta[2] counts flagged buckets).
 __global__ void k_table_dry(TableView t, const uint64_t* keys, const uint32_t* counts, uint64_t n,
                             uint32_t* caps, uint32_t* pair_ctr, unsigned long long* meta) {
+  unsigned long long flagged = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t K = keys[i];
@@ -251,9 +252,11 @@ __global__ void k_table_dry(TableView t, const uint64_t* keys, const uint32_t* c
       const uint32_t sh = 8u * (uint32_t)(pair & 3);
       const uint32_t old = atomicAdd(&pair_ctr[pair >> 2], 1u << sh);
       if (((old >> sh) & 0xFFu) >= 2u && cap_gen(caps[g.bucket]) < CAP_MAX_GEN)
-        if (!(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW)) atomicAdd(&meta[2], 1ull);
+        flagged += !(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW);
     }
   }
+  for (int o = 32; o > 0; o >>= 1) flagged += __shfl_xor(flagged, o);
+  if ((threadIdx.x & 63) == 0 && flagged) atomicAdd(&meta[2], flagged);
 }
 
 // Insert pass: one record per thread, entered under the group of each orientation into the
