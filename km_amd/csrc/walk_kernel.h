@@ -182,22 +182,28 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
   const uint32_t nwords = (uint32_t)((L + 31) >> 5);
   const uint32_t n_ref = (L >= (uint64_t)a.tab.k) ? (uint32_t)(L - a.tab.k + 1) : 0;
   uint32_t bad = 0;
-  for (uint32_t w = lane; w <= nwords; w += 64) {
-    uint64_t v = 0;
-    if (w < nwords) {
-      const uint64_t p0 = (uint64_t)w << 5;
-#pragma unroll 8
-      for (uint32_t j = 0; j < 32; ++j) {
-        uint32_t code = 0;
-        if (p0 + j < L) {
-          const uint32_t ch = a.bases[off + p0 + j] & 0xDFu;   // upper-case
-          bad |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
-          code = ((ch >> 1) ^ (ch >> 2)) & 3u;
-        }
-        v = (v << 2) | code;
+  // 256 bases per round: a lane packs 4 consecutive bases into one byte, eight neighbouring
+  // lanes are OR-ed into one 32-base word (bases past the end count as A = 0, which also
+  // writes the extra zero word)
+  for (uint32_t c = 0; c * 8 <= nwords; ++c) {
+    const uint64_t p = (uint64_t)c * 256 + lane * 4;
+    uint32_t byte = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      uint32_t code = 0;
+      if (p + j < L) {
+        const uint32_t ch = a.bases[off + p + j] & 0xDFu;       // upper-case
+        bad |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
+        code = ((ch >> 1) ^ (ch >> 2)) & 3u;
       }
+      byte = (byte << 2) | code;
     }
-    a.packed[wo + w] = v;
+    uint64_t v = (uint64_t)byte << (56 - 8 * (lane & 7));
+    v |= __shfl_xor(v, 1);
+    v |= __shfl_xor(v, 2);
+    v |= __shfl_xor(v, 4);
+    const uint32_t w = c * 8 + (lane >> 3);
+    if ((lane & 7) == 0 && w <= nwords) a.packed[wo + w] = v;
   }
   const uint64_t fwo = a.fw_off[t];
   for (uint32_t w = lane; w < (n_ref + 31) / 32; w += 64) a.flagbits[fwo + w] = 0;
