@@ -125,8 +125,14 @@ __host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t word
   return walk_lds_bytes(hs_cap, words_cap, bcap) + walk_frame_bytes(fcap);
 }
 
+// Home slot in an LDS key set.  A cheap 32-bit mix (two multiplies) instead of a 64-bit
+// finaliser: these sets are built and probed hundreds of times per target, and every
+// instruction of k_dfs sits on one wave's critical path.
 __device__ inline uint32_t set_home(uint64_t key, uint32_t cap) {
-  return (uint32_t)(((mix64(key) >> 32) * (uint64_t)cap) >> 32);
+  uint32_t h = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
+  h *= 0x9E3779B1u;
+  h ^= h >> 15;
+  return __umulhi(h, cap);
 }
 
 // Per-lane insert (distinct lanes may insert concurrently).  Returns the slot;
