@@ -502,6 +502,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
   if (!r.status || !r.n_ref || !r.node_off || !r.node_kmer || !r.node_count || !r.path_off || !r.run_off ||
       !r.run_start || !r.run_len || !r.path_min_cov || (in->n_targets && (!in->bases || !in->base_off || !in->names)))
     return KM_E_ARG;
+  if (in->k < 2 || in->k > 32) return KM_E_K;
   const uint32_t n = in->n_targets;
   uint64_t* row_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n + 1));
   int32_t* err = (int32_t*)malloc(sizeof(int32_t) * std::max<size_t>(1, n));
@@ -520,7 +521,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
           err[ti] = 0;
           if (r.status[ti] != KM_T_OK) continue;
           Target t;
-          t.name = in->names[ti];
+          t.name = in->names[ti] ? in->names[ti] : "";
           t.seq = (const char*)in->bases + in->base_off[ti];
           t.seq_len = (size_t)(in->base_off[ti + 1] - in->base_off[ti]);
           t.k = in->k;
