@@ -11,9 +11,9 @@
 //   cluster_groups              <- km/utils/MutationFinder.py:651-723
 //   target rows + their order   <- km/utils/MutationFinder.py:575-648, 726-833,
 //                                  km/utils/PathQuant.py:37-49
-// The least-squares start is solved through the eigen-decomposition of A^T A (minimum-norm
-// solution, numpy's rcond=None cut-off) instead of LAPACK's SVD: the two agree to ~1e-13
-// relative, far inside the printed %.3f / %.1f.
+// The least-squares start is the minimum-norm solution through a one-sided Jacobi SVD with
+// numpy's rcond=None cut-off; it agrees with LAPACK's gelsd to ~1e-13 relative, far inside the
+// printed %.3f / %.1f — except on rounding ties and near-singular fits, which are flagged.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -29,6 +29,9 @@
 #include "../../include/kmgpu.h"
 
 namespace {
+
+// set while formatting a target whose printed values depend on the last bits of the solver
+thread_local bool g_tie = false;
 
 typedef std::vector<int64_t> Path;
 
@@ -155,43 +158,49 @@ int name_variant(const Target& t, const Path& ref, const Path& alt, int64_t offs
   return 0;
 }
 
-// Symmetric eigen-decomposition (cyclic Jacobi), m small.  a is destroyed; v gets the
-// eigenvectors in its columns.
-void jacobi(std::vector<double>& a, int m, std::vector<double>& v, std::vector<double>& eig) {
+// Thin SVD of the n x m matrix held column by column in u (m small) by one-sided Jacobi
+// rotations (Hestenes): on return the columns of u are sigma_j * u_j, v holds the right
+// singular vectors in its columns and sig the singular values.  Works on A itself — forming
+// A^T A would square the condition number and make an exactly rank-deficient problem (a tandem
+// duplication path next to its double: sigma_3 ~ 1e-15) look full rank.
+void jacobi_svd(std::vector<std::vector<double>>& u, int m, std::vector<double>& v, std::vector<double>& sig) {
+  const size_t n = m ? u[0].size() : 0;
   v.assign((size_t)m * m, 0.0);
   for (int i = 0; i < m; ++i) v[(size_t)i * m + i] = 1.0;
-  for (int sweep = 0; sweep < 64; ++sweep) {
-    double off = 0.0;
-    for (int p = 0; p < m; ++p)
-      for (int q = p + 1; q < m; ++q) off += a[(size_t)p * m + q] * a[(size_t)p * m + q];
-    if (off == 0.0) break;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
     for (int p = 0; p < m; ++p)
       for (int q = p + 1; q < m; ++q) {
-        const double apq = a[(size_t)p * m + q];
-        if (apq == 0.0) continue;
-        const double app = a[(size_t)p * m + p], aqq = a[(size_t)q * m + q];
-        const double theta = (aqq - app) / (2.0 * apq);
-        const double tt = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(tt * tt + 1.0), s = tt * c;
-        for (int r = 0; r < m; ++r) {
-          const double arp = a[(size_t)r * m + p], arq = a[(size_t)r * m + q];
-          a[(size_t)r * m + p] = c * arp - s * arq;
-          a[(size_t)r * m + q] = s * arp + c * arq;
+        double alpha = 0, beta = 0, gamma = 0;
+        for (size_t i = 0; i < n; ++i) {
+          alpha += u[(size_t)p][i] * u[(size_t)p][i];
+          beta += u[(size_t)q][i] * u[(size_t)q][i];
+          gamma += u[(size_t)p][i] * u[(size_t)q][i];
+        }
+        if (gamma == 0.0 || std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (size_t i = 0; i < n; ++i) {
+          const double up = u[(size_t)p][i], uq = u[(size_t)q][i];
+          u[(size_t)p][i] = c * up - sn * uq;
+          u[(size_t)q][i] = sn * up + c * uq;
         }
         for (int r = 0; r < m; ++r) {
-          const double apr = a[(size_t)p * m + r], aqr = a[(size_t)q * m + r];
-          a[(size_t)p * m + r] = c * apr - s * aqr;
-          a[(size_t)q * m + r] = s * apr + c * aqr;
-        }
-        for (int r = 0; r < m; ++r) {
-          const double vrp = v[(size_t)r * m + p], vrq = v[(size_t)r * m + q];
-          v[(size_t)r * m + p] = c * vrp - s * vrq;
-          v[(size_t)r * m + q] = s * vrp + c * vrq;
+          const double vp = v[(size_t)r * m + p], vq = v[(size_t)r * m + q];
+          v[(size_t)r * m + p] = c * vp - sn * vq;
+          v[(size_t)r * m + q] = sn * vp + c * vq;
         }
       }
+    if (!rotated) break;
   }
-  eig.resize((size_t)m);
-  for (int i = 0; i < m; ++i) eig[(size_t)i] = a[(size_t)i * m + i];
+  sig.resize((size_t)m);
+  for (int j = 0; j < m; ++j) {
+    double s2 = 0;
+    for (size_t i = 0; i < n; ++i) s2 += u[(size_t)j][i] * u[(size_t)j][i];
+    sig[(size_t)j] = std::sqrt(s2);
+  }
 }
 
 // km_amd/report.py: fit_paths.  counts: float32 values of the node counts followed by -1, -1
@@ -203,31 +212,27 @@ void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& 
   std::vector<std::vector<int32_t>> col((size_t)m, std::vector<int32_t>((size_t)n_total, 0));
   for (int c = 0; c < m; ++c)
     for (int64_t node : *paths[(size_t)c]) col[(size_t)c][(size_t)node] += 1;
-  // rows that matter to the refinement: every node (the error term runs over all of them)
-  std::vector<double> g((size_t)m * m, 0.0), atb((size_t)m, 0.0);
-  for (int a = 0; a < m; ++a) {
-    for (int b = a; b < m; ++b) {
-      double s = 0.0;
-      for (int64_t i = 0; i < n_total; ++i) s += (double)col[(size_t)a][(size_t)i] * (double)col[(size_t)b][(size_t)i];
-      g[(size_t)a * m + b] = g[(size_t)b * m + a] = s;
-    }
-    double s = 0.0;
-    for (int64_t i = 0; i < n_total; ++i) s += (double)col[(size_t)a][(size_t)i] * (double)counts[(size_t)i];
-    atb[(size_t)a] = s;
-  }
-  std::vector<double> v, eig, gg = g;
-  jacobi(gg, m, v, eig);
+  // minimum-norm least squares through the SVD, numpy's rcond=None cut-off
+  // (eps * max(n, m) * sigma_max) on the singular values
+  std::vector<std::vector<double>> u((size_t)m, std::vector<double>((size_t)n_total));
+  for (int c = 0; c < m; ++c)
+    for (int64_t i = 0; i < n_total; ++i) u[(size_t)c][(size_t)i] = (double)col[(size_t)c][(size_t)i];
+  std::vector<double> v, sig;
+  jacobi_svd(u, m, v, sig);
   double smax = 0.0;
-  for (int i = 0; i < m; ++i) smax = std::max(smax, eig[(size_t)i] > 0 ? std::sqrt(eig[(size_t)i]) : 0.0);
+  for (double sj : sig) smax = std::max(smax, sj);
   const double cutoff = std::numeric_limits<double>::epsilon() * (double)std::max<int64_t>(n_total, m) * smax;
   std::vector<double> coef((size_t)m, 0.0);
-  for (int i = 0; i < m; ++i) {
-    const double lam = eig[(size_t)i];
-    if (!(lam > 0) || std::sqrt(lam) <= cutoff) continue;
-    double proj = 0.0;
-    for (int r = 0; r < m; ++r) proj += v[(size_t)r * m + i] * atb[(size_t)r];
-    proj /= lam;
-    for (int r = 0; r < m; ++r) coef[(size_t)r] += v[(size_t)r * m + i] * proj;
+  for (int j = 0; j < m; ++j) {
+    const double sj = sig[(size_t)j];
+    // a singular value near the cut-off, or a kept one that small, leaves the answer to the
+    // last bits of the solver: let the caller recompute this target with numpy
+    if (smax > 0 && sj > 1e-14 * smax && sj < 1e-6 * smax) g_tie = true;
+    if (!(sj > cutoff)) continue;
+    double proj = 0.0;                              // (sigma_j u_j) . b / sigma_j^2
+    for (int64_t i = 0; i < n_total; ++i) proj += u[(size_t)j][(size_t)i] * (double)counts[(size_t)i];
+    proj /= sj * sj;
+    for (int r = 0; r < m; ++r) coef[(size_t)r] += v[(size_t)r * m + j] * proj;
   }
   for (double& c : coef) if (c < 0) c = 0;
   std::vector<double> est((size_t)n_total), grad((size_t)m);
@@ -268,7 +273,6 @@ void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& 
 // a printed value can sit exactly on a rounding tie (x.x5 for %.1f): which way it falls is
 // then decided by the last-bit rounding errors of the solver.  Such rows are flagged and the
 // caller recomputes that target with numpy, whose LAPACK path is the reference's.
-thread_local bool g_tie = false;
 inline void note_tie(double v, double scale) {
   if (!(v == v) || std::fabs(v) > 1e15) return;
   const double f = std::fabs(v) * scale;

@@ -145,3 +145,26 @@ def test_native_rows_many_random_variants():
         assert got == _python_rows(res, seq, "rnd.jf")
         kinds.update(r.split("\t")[2] for r in got)
     assert {"Reference", "Substitution", "Insertion", "Deletion", "ITD"} <= kinds
+
+
+def test_native_rows_rank_deficient_cluster_fit():
+    """A tandem-duplication path next to the path that walks the duplicated stretch twice makes the
+    cluster's least-squares matrix exactly rank deficient (sigma_3 ~ 1e-15): the minimum-norm
+    answer must be numpy's (found by tools/soak.py; solving through A^T A kept the null direction)."""
+    from oracle import c_oracle
+    k = 32
+    case = synth.make_case(n_targets=1500, length=200, k=k, n_keys=200_000, seed=1028014213,
+                           variant_frac=0.7, cov=(50, 2000), exact_pad=False)
+    co = c_oracle.COracle(case["keys"][:case["n_real"]], case["counts"][:case["n_real"]], k)
+    results, names, seqs = [], [], []
+    for t in range(150, 260):
+        w = co.analyse(case["targets"][t], max_stack=60, max_break=3)
+        results.append({"name": case["names"][t], "k": k, "n_ref": w["n_ref"],
+                        "kmers": [km.unpack(int(x), k) for x in w["kmers"]], "counts": w["counts"].tolist(),
+                        "paths": w["paths"], "min_cov": w["min_cov"], "probes": w["probes"]})
+        names.append(case["names"][t])
+        seqs.append(km.decode(case["targets"][t]))
+    assert "syn_t00194" in names
+    blocks = kmlib.report_rows(_raw_from_oracle(results), names, seqs, k, "soak.jf")
+    for res, seq, got in zip(results, seqs, blocks):
+        assert got == _python_rows(res, seq, "soak.jf"), res["name"]

@@ -1,0 +1,61 @@
+"""Soak: many seeded synthetic batches (different seeds, k, coverages, walk budgets) through the
+HIP path, every target checked against the plain-C oracle (test infrastructure) and the native
+rows against the Python reporting.  Usage on the GPU box: python tools/soak.py [rounds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge  # noqa: E402
+
+ge.build()
+from km_amd import kmer as km, lib as kmlib, report, synth  # noqa: E402
+from km_amd.finder import BatchFinder  # noqa: E402
+from km_amd.jellyfish import Jellyfish  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+rng = np.random.default_rng(20261004)
+bad = 0
+for rd in range(rounds):
+    seed = int(rng.integers(1, 1 << 30))
+    k = int(rng.choice([21, 25, 31, 31, 31, 32]))
+    n = int(rng.choice([600, 1500]))
+    length = int(rng.choice([200, 350, 500]))
+    cov = (20, 300) if rng.random() < 0.3 else (50, 2000)
+    case = synth.make_case(n_targets=n, length=length, k=k, n_keys=int(rng.choice([200_000, 1_500_000])), seed=seed,
+                           variant_frac=float(rng.choice([0.3, 0.7])), cov=cov, exact_pad=False)
+    t0 = time.perf_counter()
+    db = kmlib.Database.from_records(case["keys"], case["counts"], k).upload(0)
+    steps, branchs = (int(rng.choice([500, 60])), int(rng.choice([10, 3])))
+    b = kmlib.Batch(db, max_stack=steps, max_break=branchs, max_targets=n, max_total_bases=n * length)
+    b.set_targets([km.decode(r) for r in case["targets"]])
+    b.run()
+    r = b.fetch()
+    co = c_oracle.COracle(case["keys"][:case["n_real"]], case["counts"][:case["n_real"]], k)
+    noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
+    mism = 0
+    for t in range(n):
+        want = co.analyse(case["targets"][t], max_stack=steps, max_break=branchs)
+        ok = (want["status"] == int(r["status"][t]) == 0
+              and (r["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all()
+              and (r["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all()
+              and int(r["probes"][t]) == want["probes"]
+              and [kmlib.expand_path(r, p).tolist() for p in range(poff[t], poff[t + 1])] == want["paths"]
+              and r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"])
+        mism += not ok
+    # native vs python reporting on the same fetched arrays
+    jf = Jellyfish("soak.jf", cutoff=0.05, n_cutoff=5, db=db)
+    finder = BatchFinder(jf, steps, branchs, 10000)
+    targets = [(nm, km.decode(rw)) for nm, rw in zip(case["names"], case["targets"])]
+    native = finder.rows(targets[:400])
+    python = [report.target_rows(res, jf.filename) for res in finder.analyse(targets[:400])]
+    rep_mism = sum(a != b_ for a, b_ in zip(native, python))
+    bad += mism + rep_mism
+    print("round %d seed %d k %d n %d len %d steps %d/%d: walk/path mismatches %d, report mismatches %d, "
+          "max_probe %d, %.1f s" % (rd, seed, k, n, length, steps, branchs, mism, rep_mism, db.info.max_probe,
+                                    time.perf_counter() - t0), flush=True)
+print("SOAK", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
