@@ -25,12 +25,17 @@ for rd in range(rounds):
     n = int(rng.choice([600, 1500]))
     length = int(rng.choice([200, 350, 500]))
     cov = (20, 300) if rng.random() < 0.3 else (50, 2000)
+    multi = rng.random() < 0.4                      # several variants per target, homozygous ones, dead-end branches
     case = synth.make_case(n_targets=n, length=length, k=k, n_keys=int(rng.choice([200_000, 1_500_000])), seed=seed,
-                           variant_frac=float(rng.choice([0.3, 0.7])), cov=cov, exact_pad=False)
+                           variant_frac=float(rng.choice([0.3, 0.7, 1.0])), cov=cov, exact_pad=False,
+                           variants_per_target=(1, 3) if multi else (1, 1), hom_frac=0.25 if multi else 0.0,
+                           branch_noise_frac=0.03 if multi else 0.0, noise_frac=0.03 if multi else 0.01)
+    ratio, count = float(rng.choice([0.05, 0.05, 0.2, 0.01])), int(rng.choice([5, 5, 2, 30]))
     t0 = time.perf_counter()
     db = kmlib.Database.from_records(case["keys"], case["counts"], k).upload(0)
     steps, branchs = (int(rng.choice([500, 60])), int(rng.choice([10, 3])))
-    b = kmlib.Batch(db, max_stack=steps, max_break=branchs, max_targets=n, max_total_bases=n * length)
+    b = kmlib.Batch(db, ratio=ratio, count=count, max_stack=steps, max_break=branchs, max_targets=n,
+                    max_total_bases=n * length)
     b.set_targets([km.decode(r) for r in case["targets"]])
     b.run()
     r = b.fetch()
@@ -38,7 +43,7 @@ for rd in range(rounds):
     noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
     mism = 0
     for t in range(n):
-        want = co.analyse(case["targets"][t], max_stack=steps, max_break=branchs)
+        want = co.analyse(case["targets"][t], ratio=ratio, count=count, max_stack=steps, max_break=branchs)
         ok = (want["status"] == int(r["status"][t]) == 0
               and (r["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all()
               and (r["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all()
@@ -47,15 +52,15 @@ for rd in range(rounds):
               and r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"])
         mism += not ok
     # native vs python reporting on the same fetched arrays
-    jf = Jellyfish("soak.jf", cutoff=0.05, n_cutoff=5, db=db)
+    jf = Jellyfish("soak.jf", cutoff=ratio, n_cutoff=count, db=db)
     finder = BatchFinder(jf, steps, branchs, 10000)
     targets = [(nm, km.decode(rw)) for nm, rw in zip(case["names"], case["targets"])]
     native = finder.rows(targets[:400])
     python = [report.target_rows(res, jf.filename) for res in finder.analyse(targets[:400])]
     rep_mism = sum(a != b_ for a, b_ in zip(native, python))
     bad += mism + rep_mism
-    print("round %d seed %d k %d n %d len %d steps %d/%d: walk/path mismatches %d, report mismatches %d, "
-          "max_probe %d, %.1f s" % (rd, seed, k, n, length, steps, branchs, mism, rep_mism, db.info.max_probe,
+    print("round %d seed %d k %d n %d len %d -p %g -c %d multi %d steps %d/%d: walk/path mismatches %d, report mismatches %d, "
+          "max_probe %d, %.1f s" % (rd, seed, k, n, length, ratio, count, multi, steps, branchs, mism, rep_mism, db.info.max_probe,
                                     time.perf_counter() - t0), flush=True)
 print("SOAK", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
