@@ -26,9 +26,11 @@ for rd in range(rounds):
     length = int(rng.choice([200, 350, 500]))
     cov = (20, 300) if rng.random() < 0.3 else (50, 2000)
     multi = rng.random() < 0.4                      # several variants per target, homozygous ones, dead-end branches
+    heavy = rng.random() < 0.15 or bool(os.environ.get("SOAK_HEAVY"))   # 3-5 tandem duplications: the large tier
     case = synth.make_case(n_targets=n, length=length, k=k, n_keys=int(rng.choice([200_000, 1_500_000])), seed=seed,
                            variant_frac=float(rng.choice([0.3, 0.7, 1.0])), cov=cov, exact_pad=False,
-                           variants_per_target=(1, 3) if multi else (1, 1), hom_frac=0.25 if multi else 0.0,
+                           variants_per_target=(3, 5) if heavy else ((1, 3) if multi else (1, 1)),
+                           kinds=("dup",) if heavy else ("snv", "ins", "del", "dup"), hom_frac=0.25 if multi else 0.0,
                            branch_noise_frac=0.03 if multi else 0.0, noise_frac=0.03 if multi else 0.01)
     ratio, count = float(rng.choice([0.05, 0.05, 0.2, 0.01])), int(rng.choice([5, 5, 2, 30]))
     t0 = time.perf_counter()
@@ -60,7 +62,7 @@ for rd in range(rounds):
     rep_mism = sum(a != b_ for a, b_ in zip(native, python))
     bad += mism + rep_mism
     print("round %d seed %d k %d n %d len %d -p %g -c %d multi %d steps %d/%d: walk/path mismatches %d, report mismatches %d, "
-          "max_probe %d, %.1f s" % (rd, seed, k, n, length, ratio, count, multi, steps, branchs, mism, rep_mism, db.info.max_probe,
+          "large tier %d, max_probe %d, %.1f s" % (rd, seed, k, n, length, ratio, count, multi, steps, branchs, mism, rep_mism, int(r["n_big_tier"]), db.info.max_probe,
                                     time.perf_counter() - t0), flush=True)
 print("SOAK", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
