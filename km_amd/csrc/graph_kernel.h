@@ -64,7 +64,7 @@ struct GraphArgs {
   const uint32_t* tflag;     // target has flagged seeds (its node list comes from k_dfs)
   uint32_t* need_full;       // k_graph_pure -> k_graph: target needs the general algorithm
   uint32_t use_need_full;    // k_graph: skip targets k_graph_pure already answered
-  uint32_t hcap_pure;        // k_graph_pure: prefix-key slots (multiple of 64)
+  uint32_t hcap_pure;        // k_graph_pure: fingerprint slots (multiple of 64)
   // outputs
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
@@ -128,50 +128,54 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   if (a.tflag[t]) return;                      // k_graph handles it once k_dfs is done
   const uint32_t n_ref = a.n_ref[t];
   const uint32_t hcap = a.hcap_pure;
-  if ((uint64_t)3 * (n_ref + 2) > (uint64_t)2 * hcap || (a.dbg != 0 && !(a.dbg & 0x80u))) {
+  if ((uint64_t)2 * (n_ref + 2) > (uint64_t)hcap || (a.dbg != 0 && !(a.dbg & 0x80u))) {
     if (tid == 0) a.need_full[t] = 1;
     return;
   }
   const uint64_t nb = a.node_base[t];
   const uint64_t* nk = a.node_kmer + nb;
   const uint32_t* ncnt = a.node_cnt + nb;
-  uint64_t* pkeys = reinterpret_cast<uint64_t*>(smem);
+  // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of
+  // the last) distinct?  A set of 32-bit FINGERPRINTS at load <= 1/4 answers it: equal
+  // (k-1)-mers always meet (same fingerprint, same home); two different ones with the same
+  // fingerprint (2.6e-5 per target) only send the target to k_graph, which decides exactly.
+  uint32_t* fps = reinterpret_cast<uint32_t*>(smem);
   {
-    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
     uint4* q = reinterpret_cast<uint4*>(smem);
-    for (uint32_t x = tid; x < hcap / 2; x += NT) q[x] = ones;
+    for (uint32_t x = tid; x < hcap / 4; x += NT) q[x] = zero;
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: LDS runs its operations in order
   uint32_t not_pure = 0;
   uint32_t mincov = 0xFFFFFFFFu;
+  auto insert = [&](uint64_t key) {
+    uint32_t fp = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
+    fp ^= fp >> 16;
+    fp = fp ? fp : 1u;
+    uint32_t s = __umulhi(fp * 0xC2B2AE35u, hcap);
+    for (uint32_t step = 0; step < hcap; ++step) {
+      const uint32_t old = atomicCAS(&fps[s], 0u, fp);
+      if (old == 0u) return;
+      if (old == fp) { not_pure = 1; return; }
+      if (++s == hcap) s = 0;
+    }
+    not_pure = 1;
+  };
   // four independent loads in flight per lane, then the (LDS-atomic) inserts
-  for (uint32_t j0 = tid; j0 < n_ref; j0 += 4 * NT) {
+  for (uint32_t j0 = tid; j0 <= n_ref; j0 += 4 * NT) {
     uint64_t kk[4];
     uint32_t cc[4];
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
       const uint32_t j = j0 + u * NT;
-      kk[u] = j < n_ref ? nk[j] : 0;
+      kk[u] = j < n_ref ? (nk[j] >> 2) : (j == n_ref ? (nk[n_ref - 1] & a.pmask) : 0);
       cc[u] = j < n_ref ? ncnt[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-      if (j0 + u * NT >= n_ref) break;
-      bool wn;
-      const int s = set_insert_lane(pkeys, hcap, kk[u] >> 2, &wn);
-      if (s < 0 || !wn) not_pure = 1;
+      if (j0 + u * NT > n_ref) break;
+      insert(kk[u]);
       mincov = cc[u] < mincov ? cc[u] : mincov;
-    }
-  }
-  __syncthreads();
-  if (tid == 0 && !not_pure) {
-    const uint64_t S = nk[n_ref - 1] & a.pmask;
-    uint32_t s = set_home(S, hcap);
-    for (uint32_t step = 0; step < hcap; ++step) {
-      const uint64_t kv = pkeys[s];
-      if (kv == S) { not_pure = 1; break; }
-      if (kv == EMPTY) break;
-      if (++s == hcap) s = 0;
     }
   }
   if (__any((int)not_pure)) {

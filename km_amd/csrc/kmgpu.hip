@@ -953,9 +953,9 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
 
 static void pure_geometry(km_batch* b) {
   const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
-  b->ga.hcap_pure = round_up((max_nref + 2) + (max_nref + 2) / 2 + 1, 64);
-  b->pure_lds = b->ga.hcap_pure * 8;
-  if (b->pure_lds > FAST_LDS_LIMIT) { b->ga.hcap_pure = 64; b->pure_lds = 512; }   // all -> need_full
+  b->ga.hcap_pure = round_up(4 * (max_nref + 2), 64);            // 32-bit fingerprints at load <= 1/4
+  b->pure_lds = b->ga.hcap_pure * 4;
+  if (b->pure_lds > FAST_LDS_LIMIT) { b->ga.hcap_pure = 64; b->pure_lds = 256; }   // all -> need_full
 }
 
 // Graph stage on one stream: pure-chain pass, then the general kernel for the rest.
