@@ -121,18 +121,19 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t lane = threadIdx.x & 63u, NT = 64;
   const uint32_t tid = lane;
   const uint32_t t = blockIdx.x;
-  if (a.status[t] != T_OK) {
+  const uint32_t h_status = a.status[t], h_tflag = a.tflag[t];   // header words requested together
+  const uint32_t n_ref = a.n_ref[t];
+  const uint64_t nb = a.node_base[t];
+  if (h_status != T_OK) {
     if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
-  if (a.tflag[t]) return;                      // k_graph handles it once k_dfs is done
-  const uint32_t n_ref = a.n_ref[t];
+  if (h_tflag) return;                         // k_graph handles it once k_dfs is done
   const uint32_t hcap = a.hcap_pure;
   if ((uint64_t)2 * (n_ref + 2) > (uint64_t)hcap || (a.dbg != 0 && !(a.dbg & 0x80u))) {
     if (tid == 0) a.need_full[t] = 1;
     return;
   }
-  const uint64_t nb = a.node_base[t];
   const uint64_t* nk = a.node_kmer + nb;
   const uint32_t* ncnt = a.node_cnt + nb;
   // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of
@@ -226,20 +227,23 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   unsigned long long* ctr = a.counters + (uint64_t)pg * POOL_CTR_STRIDE;
   unsigned long long* ovf = a.counters + (uint64_t)POOL_GROUPS * POOL_CTR_STRIDE;
 
-  if (a.status[t] != T_OK) {
+  // the per-target header words, requested together (the early exits below would otherwise
+  // chain them into four dependent round trips)
+  const uint32_t h_status = a.status[t], h_tflag = a.tflag[t], h_need = a.need_full[t];
+  const uint32_t m = a.n_nodes[t];
+  const uint32_t n_ref = a.n_ref[t];
+  const uint64_t nb = a.node_base[t];
+  if (h_status != T_OK) {
     if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
-  if (a.use_need_full && !a.tflag[t] && !a.need_full[t]) return;   // answered by k_graph_pure
-  const uint32_t m = a.n_nodes[t];
-  const uint32_t n_ref = a.n_ref[t];
+  if (a.use_need_full && !h_tflag && !h_need) return;   // answered by k_graph_pure
   const uint32_t n = m + 2, src = m, snk = m + 1;
   const uint32_t ncap = a.ncap, hcap = a.hcap;
   if (n > ncap || (uint64_t)3 * n > (uint64_t)2 * hcap || (!BIG && n >= 0xFFFFu)) {
     if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
     return;
   }
-  const uint64_t nb = a.node_base[t];
   const uint64_t* nk = a.node_kmer + nb;
   const uint32_t* ncnt = a.node_cnt + nb;
   const int k = a.k;
