@@ -2,22 +2,33 @@
 """Benchmark of the find_mutation hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[3]): per GPU 10 000 random
-500-nt targets, k=31, against ONE table of 100 M distinct canonical 31-mers
-resident in HBM.  A step = one pass of the hot path (walk kernel + path-search
-kernel) over the GPU's 10 000 targets; targets and table are in HBM before the
-timed region starts.  With N > 1 the table records are broadcast once over RCCL
-(torch.distributed) and every rank builds its own table; targets are sharded by
-rank, no further collectives (weak scaling: per-GPU work fixed).
+Workload (BASELINE.json configs[3]): 10 000 random 500-nt targets per step,
+k=31, against ONE table of 100 M distinct canonical 31-mers resident in HBM.
+
+A step = one pass of the hot path over one 10 000-target batch: k_pack + k_seed + k_dfs (walk),
+k_graph_pure + k_graph (path search), device-side compaction of the results and their D2H copy
+into pinned host memory.  `value` = targets/s of the whole pipeline INCLUDING result delivery
+(targets/s = n_targets / (walk + graph kernels + D2H)); the kernel-only rate is
+reported beside it.  Targets and table are in HBM before the timed region starts.  The
+`--inflight` workspaces each hold a DIFFERENT 10 000-target set (working set >> the 256 MiB
+Infinity Cache), and the run checks 200 targets against the plain-C oracle given the full key
+set, exiting non-zero on a mismatch.
+
+With --gpus N > 1 and no torchrun environment the script starts N ranks itself
+(python -m torch.distributed.run, before any GPU call) and relays rank 0's JSON line.  The table
+records cross the links once (RCCL broadcast, every rank builds its own table); targets are
+sharded by rank, no collective on the data path.  `value` is weak scaling (10 000 targets per
+GPU per step); BASELINE config 4 proper (10 000 targets sharded over the N GPUs) is reported
+under "config4_strong".
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,65 +39,162 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_PROBE = 12           # 8-byte key + 4-byte count
+K = 31
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(case, n_sample, k):
-    """The oracle (structure-faithful Python restatement of the reference path)
-    timed on one host core over the first `n_sample` targets of this workload."""
-    from km_amd import kmer as km
+# ---------------------------------------------------------------------------- CPU baseline
+_CPU = {}
+
+
+def _cpu_init(case, n_need):
     from oracle import km_oracle as ko
     nr = case["n_real"]
-    # The first n_real records are the non-pad keys, each tagged with the target it was
-    # generated for; random pad 31-mers never touch a walk, and the k-mers of other targets
-    # do not either (independent random sequences), so the oracle only needs the keys of
-    # the targets it is timed on.
-    n_need = min(len(case["targets"]), 4 * n_sample)
+    # the non-pad keys of the sampled targets (the oracle's dict cannot hold 100 M keys in every
+    # worker; a walk that reached a key outside this subset would differ from the GPU's, which the
+    # in-run check — full key set — would catch)
     sel = case["key_target"] < n_need
-    rec = {"k": k, "canonical": True, "keys": case["keys"][:nr][sel], "counts": case["counts"][:nr][sel]}
-    db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records=rec)
-    t0 = time.perf_counter()
+    rec = {"k": K, "canonical": True, "keys": case["keys"][:nr][sel], "counts": case["counts"][:nr][sel]}
+    _CPU["db"] = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records=rec)
+    _CPU["case"] = case
+    _CPU["n_keys"] = int(sel.sum())
+
+
+def _cpu_work(span):
+    from km_amd import kmer as km
+    from oracle import km_oracle as ko
+    case, db = _CPU["case"], _CPU["db"]
     probes = 0
-    rows = 0
-    for i in range(n_sample):
-        seq = km.decode(case["targets"][i])
-        res = ko.analyse_target(seq, case["names"][i], db)
+    t0 = time.perf_counter()
+    for i in range(*span):
+        res = ko.analyse_target(km.decode(case["targets"][i]), case["names"][i], db)
         probes += res["probes"]
-        rows += len(res["paths"])
-    dt = time.perf_counter() - t0
+    return probes, time.perf_counter() - t0
+
+
+def cpu_baseline(case, n_sample):
+    """The oracle (structure-faithful Python restatement of the reference path: str k-mers, one
+    lookup per query, recursive extend, dense numpy Dijkstra) timed on the host: one core (the
+    reference is single-threaded) and all cores (one process per core, targets sharded).  Must
+    run BEFORE this process touches the GPU (it forks)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    per = max(8, n_sample // 4)
+    n_all = per * cores
+    n_need = min(len(case["targets"]), max(n_sample, n_all))
+    _cpu_init(case, n_need)
+    n_sample = min(n_sample, n_need)
+    probes, dt = _cpu_work((0, n_sample))
+    out = {"value": n_sample / dt, "unit": "targets/s", "cores": 1, "kind": "port",
+           "sample": "first %d of the targets of set 0 (walk + path search, oracle/km_oracle.py, dict-backed "
+                     "table of the %d keys the first %d targets touch)" % (n_sample, _CPU["n_keys"], n_need),
+           "probes_per_s": probes / dt, "seconds": dt}
+    try:
+        ctx = mp.get_context("fork")
+        spans = [(c * per, min(n_need, (c + 1) * per)) for c in range(cores)]
+        spans = [s for s in spans if s[1] > s[0]]
+        t0 = time.perf_counter()
+        with ctx.Pool(len(spans)) as pool:
+            parts = pool.map(_cpu_work, spans)
+        wall = time.perf_counter() - t0
+        n_done = sum(s[1] - s[0] for s in spans)
+        out["all_cores"] = {"cores": len(spans), "value": n_done / wall, "unit": "targets/s",
+                            "sample": "%d targets, %d per process" % (n_done, per), "seconds": wall,
+                            "probes_per_s": sum(p for p, _ in parts) / wall}
+    except Exception as e:                      # pragma: no cover
+        out["all_cores"] = {"error": repr(e)}
     # the same work through the plain-C oracle (oracle/km_oracle.c), for scale
-    c_rate = None
     try:
         from oracle import c_oracle
-        co = c_oracle.COracle(rec["keys"], rec["counts"], k)
-        n_c = n_need
-        t1 = time.perf_counter()
-        for i in range(n_c):
-            co.analyse(case["targets"][i])
-        c_rate = n_c / (time.perf_counter() - t1)
-    except Exception as e:          # the C oracle is optional test infrastructure
+        db = _CPU["db"]
+        co = c_oracle.COracle(np.fromiter(db.table.keys(), dtype=np.uint64, count=len(db.table)),
+                              np.fromiter(db.table.values(), dtype=np.uint32, count=len(db.table)), K) \
+            if hasattr(db, "table") else None
+        if co is not None:
+            t1 = time.perf_counter()
+            for i in range(n_need):
+                co.analyse(case["targets"][i])
+            out["c_oracle_targets_per_s"] = n_need / (time.perf_counter() - t1)
+    except Exception as e:
         log("C oracle not timed:", e)
-    return {"value": n_sample / dt, "unit": "targets/s", "cores": 1, "kind": "port",
-            "c_oracle_targets_per_s": c_rate,
-            "sample": "first %d of the 10000 targets (walk + path search, oracle/km_oracle.py, "
-                      "dict-backed table of the %d keys those targets touch)" % (n_sample, int(sel.sum())),
-            "probes_per_s": probes / dt, "seconds": dt}
+    _CPU.clear()
+    return out
+
+
+# ---------------------------------------------------------------------------- workload
+def load_case(args, n_targets):
+    from km_amd import synth
+    tag = "%s/case_%d_%d_%d" % (args.cache, n_targets, args.length, args.keys)
+    fields = ("keys", "counts", "targets", "key_target")
+    if args.cache and os.path.exists(tag + "_keys.npy"):
+        case = {f: np.load("%s_%s.npy" % (tag, f)) for f in fields}
+        meta = json.load(open(tag + "_meta.json"))
+        case.update(k=K, n_real=meta["n_real"], names=meta["names"])
+        return case
+    case = synth.make_case(n_targets=n_targets, length=args.length, k=K, n_keys=args.keys,
+                           seed=synth.HEADLINE_SEED, exact_pad=False)
+    if args.cache:
+        os.makedirs(args.cache, exist_ok=True)
+        for f in fields:
+            np.save("%s_%s.npy" % (tag, f), case[f])
+        json.dump({"n_real": int(case["n_real"]), "names": list(case["names"])}, open(tag + "_meta.json", "w"))
+    return case
+
+
+def oracle_check(case, views, set_ids, T, n_check):
+    """`n_check` targets spread over the delivered batches against the plain-C oracle holding
+    EVERY key of the table (pads included: a random pad 31-mer can neighbour a walk)."""
+    from km_amd import lib as kmlib
+    from oracle import c_oracle
+    t0 = time.perf_counter()
+    co = c_oracle.COracle(case["keys"], case["counts"], K)
+    t_build = time.perf_counter() - t0
+    ref = None
+    n_done = n_multi = 0
+    per = max(1, n_check // len(views))
+    for v, sid in zip(views, set_ids):
+        noff, xoff, poff = (v[x].astype(np.int64) for x in ("node_off", "extra_off", "path_off"))
+        for t in range(0, T, max(1, T // per)):
+            g = sid * T + t
+            want = co.analyse(case["targets"][g])
+            ok = int(v["status"][t]) == want["status"] == 0
+            nr = int(v["n_ref"][t])
+            ok = ok and (v["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all()
+            ok = ok and (v["extra_kmer"][xoff[t]:xoff[t + 1]] == want["kmers"][nr:]).all()
+            ok = ok and int(v["probes"][t]) == want["probes"]
+            got = [kmlib.expand_path(v, p).tolist() for p in range(poff[t], poff[t + 1])]
+            ok = ok and got == want["paths"]
+            ok = ok and v["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"]
+            if not ok:
+                return {"ok": False, "first_mismatch": {"set": sid, "target": t}, "checked": n_done}
+            n_done += 1
+            n_multi += len(got) > 1
+    return {"ok": True, "checked": n_done, "with_variant_paths": n_multi, "oracle": "oracle/km_oracle.c",
+            "oracle_keys": int(len(case["keys"])), "oracle_build_s": t_build}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--targets", type=int, default=10000, help="targets per GPU")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--targets", type=int, default=10000, help="targets per GPU per step")
     ap.add_argument("--length", type=int, default=500)
     ap.add_argument("--keys", type=int, default=100_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=300)
+    ap.add_argument("--cpu-sample", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify a sample against the oracle")
+    ap.add_argument("--check", type=int, default=200, help="targets checked against the C oracle (0 = off)")
     ap.add_argument("--e2e", type=int, default=10000,
                     help="targets for the end-to-end (strings in -> TSV rows out) measurement")
     ap.add_argument("--hipgraph", action="store_true",
@@ -94,20 +202,42 @@ def main():
     ap.add_argument("--walk-only", action="store_true", help="time the walk stage only (ablations)")
     ap.add_argument("--only-step", action="store_true",
                     help="skip the side measurements (end-to-end host path, probe kernels, one-target "
-                         "latency): every launch in a profile of this run is a 10 000-target launch")
+                         "latency, ingestion): every launch in a profile of this run is a 10 000-target launch")
     ap.add_argument("--no-ingest", dest="ingest", action="store_false",
                     help="skip the .jf ingestion measurement (writes a 1.2 GB file to the temp dir)")
-    ap.add_argument("--cache", default="", help="directory to keep the generated workload in "
-                    "(re-used by later invocations with the same sizes)")
+    ap.add_argument("--cache", default="", help="directory to keep the generated workload in")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
+
+    # ---- N > 1 without a torchrun environment: start the ranks ourselves, before any GPU call
+    if args.gpus > 1 and "RANK" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    T = args.targets
+    n_fl = max(1, args.inflight)
+    both_names = "walk" if args.walk_only else "walk+graph"
+
+    # ---- rank 0: workload + CPU baseline, BEFORE this process touches the GPU ----------------
+    t_gen = time.perf_counter()
+    case = load_case(args, T * n_fl) if rank == 0 else None
+    t_gen = time.perf_counter() - t_gen
+    cpu = None
+    if rank == 0:
+        import __graft_entry__ as ge
+        ge.build()
+        if not args.no_cpu and world == 1:
+            cpu = cpu_baseline(case, min(args.cpu_sample, T))
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -118,47 +248,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
         dist.barrier()
+    from km_amd import dist as kd
     from km_amd import lib as kmlib
     from km_amd import synth
 
-    K = 31
-    T = args.targets
-    # ---- rank 0 generates the whole job: world*T targets, one table --------------------
-    t_gen = time.perf_counter()
-    case = None
-    if rank == 0:
-        tag = "%s/case_%d_%d_%d" % (args.cache, T * world, args.length, args.keys)
-        fields = ("keys", "counts", "targets", "key_target")
-        if args.cache and os.path.exists(tag + "_keys.npy"):
-            case = {f: np.load("%s_%s.npy" % (tag, f)) for f in fields}
-            meta = json.load(open(tag + "_meta.json"))
-            case.update(k=K, n_real=meta["n_real"], names=meta["names"])
-        else:
-            case = synth.make_case(n_targets=T * world, length=args.length, k=K, n_keys=args.keys,
-                                   seed=synth.HEADLINE_SEED, exact_pad=False)
-            if args.cache:
-                os.makedirs(args.cache, exist_ok=True)
-                for f in fields:
-                    np.save("%s_%s.npy" % (tag, f), case[f])
-                json.dump({"n_real": int(case["n_real"]), "names": list(case["names"])},
-                          open(tag + "_meta.json", "w"))
-    t_gen = time.perf_counter() - t_gen
-
-    # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------
-    from km_amd import dist as kd
+    # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------------
     t_up = time.perf_counter()
     d_keys, d_cnts, n_rec, _k, _canon = kd.broadcast_records(
         case["keys"] if rank == 0 else None, case["counts"] if rank == 0 else None, K, True, dev)
     if rank == 0:
         bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(dev)
     else:
-        bases_all = torch.empty((T * world, args.length), dtype=torch.uint8, device=dev)
+        bases_all = torch.empty((T * n_fl, args.length), dtype=torch.uint8, device=dev)
     if world > 1:
         dist.broadcast(bases_all, 0)
     torch.cuda.synchronize()
@@ -170,90 +272,134 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     info = db.info
-    # a resident sample of stored k-mers for the probe-only microbenchmark below
     n_probe = int(min(n_rec, T * (args.length - K + 1)))
     d_probe = d_keys[torch.randperm(n_rec, device=dev)[:n_probe]].contiguous() if rank == 0 else None
     del d_keys, d_cnts
     torch.cuda.empty_cache()
 
-    # ---- this rank's shard of targets, resident in HBM -----------------------------------
-    mine = bases_all[rank * T:(rank + 1) * T].contiguous()
+    # ---- the box's large-copy bandwidth (device-to-device), beside the 8 TB/s spec -------------
+    d2d = None
+    if rank == 0:
+        a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        b_ = torch.empty_like(a_)
+        b_.copy_(a_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize()
+        d2d = 2 * 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write
+        del a_, b_
+        torch.cuda.empty_cache()
+
+    # ---- workspaces: `inflight` of them, each with its own HIP stream and its OWN target set ---
+    # (weak scaling: every rank steps through the same n_fl sets, rotated by its rank)
     offsets = (np.arange(T + 1, dtype=np.uint64) * np.uint64(args.length))
-    # `inflight` independent workspaces, each with its own HIP stream: while one batch is in
-    # its latency-bound kernels (k_dfs, k_graph) the next one runs its HBM-bound k_seed
-    n_fl = max(1, args.inflight)
     tstreams = [torch.cuda.Stream(device=dev) for _ in range(n_fl)]
+    set_ids = [(q + rank) % n_fl for q in range(n_fl)]
     batches = []
     for q in range(n_fl):
         bq = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
                          max_targets=T, max_total_bases=T * args.length)
-        bq.set_targets_dev(mine.data_ptr(), offsets, stream)
+        bq.set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
         batches.append(bq)
     torch.cuda.synchronize()
-    batch = batches[0]
-    both = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH)
-    replay = (both | kmlib.KM_RUN_HIPGRAPH) if args.hipgraph else both
+    stages = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH)
+    if args.hipgraph:
+        stages |= kmlib.KM_RUN_HIPGRAPH
+    deliver = stages | kmlib.KM_RUN_DELIVER
+
+    def pipeline(n_steps, flags, wait):
+        """n_steps steps round-robin over the workspaces; before a workspace is reused (and at
+        the end) its previous delivery is awaited, i.e. its results are in pinned host memory."""
+        for i in range(n_steps):
+            q = i % n_fl
+            if wait and i >= n_fl:
+                batches[q].wait_result()
+            batches[q].run(flags, tstreams[q].cuda_stream)
+        if wait:
+            for q in range(min(n_fl, n_steps)):
+                batches[q].wait_result()
+        torch.cuda.synchronize()
 
     # ---- warm-up ---------------------------------------------------------------------------
-    for i in range(max(1, args.warmup)):
-        for q in range(n_fl):
-            batches[q].run(replay, tstreams[q].cuda_stream)
-    for bq in batches:
-        bq.sync()
-    sizes = batch.sizes()
-    probes_per_step = int(sizes.logical_probes)
-    fetches_per_step = int(sizes.table_fetches)
+    pipeline(max(n_fl, args.warmup), deliver, True)
+    sizes = [bq.wait_result() for bq in batches]
+    probes_per_step = float(np.mean([int(s.logical_probes) for s in sizes]))
+    seed_probes = float(np.mean([int(s.seed_probes) for s in sizes]))
+    fetches_per_step = float(np.mean([int(s.table_fetches) for s in sizes]))
 
-    # ---- timed region: exactly K steps (one step = one pass over one batch) ---------------
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        q = i % n_fl
-        batches[q].run(replay, tstreams[q].cuda_stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    for bq in batches:
-        bq.sync()
-    # k_seed as it ran inside the timed region (the last launch of every workspace; with
-    # several batches in flight it shares the GPU with the other batches' kernels)
-    seed_pipelined_ms = float(np.mean([bq.timings()[3] for bq in batches])) if not args.hipgraph else None
+    # ---- timed region: exactly K steps, results delivered to pinned host memory ---------------
+    def timed(flags, wait):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipeline(args.steps, flags, wait)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
 
-    # ---- latency of one isolated step (no pipelining) --------------------------------------
+    dt = timed(deliver, True)
+    # the delivered bytes of one step (region A + tail) and the delivered views for the check
+    views = [bq.result() for bq in batches]
+    out_bytes = float(np.mean([sum(v[x].nbytes for x in v if isinstance(v[x], np.ndarray)) for v in views]))
+    check = None
+    if rank == 0 and args.check > 0 and not args.walk_only:
+        check = oracle_check(case, views, set_ids, T, args.check)
+        log("oracle check:", check)
+    del views
+    # kernel-only rate (results stay in HBM): what round 1 reported as `value`
+    dt_kernel = timed(stages, False)
+
+    # ---- one step at a time (no pipelining), with and without delivery -------------------------
+    batch = batches[0]
+    st0 = tstreams[0].cuda_stream
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
-        batch.run(both, stream)
-    torch.cuda.synchronize()
+        batch.run(deliver, st0)
+        batch.wait_result()
     serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
-    batch.sync()
-
     # ---- per-kernel durations (HIP events on the launch stream), averaged over K launches
-    walk_ms, graph_ms, seed_ms = [], [], []
+    tm = []
     for _ in range(args.steps):
-        batch.run(both, stream)
-        w, g, _tot, sd = batch.timings()
-        walk_ms.append(w)
-        graph_ms.append(g)
-        seed_ms.append(sd)
-    walk_avg = float(np.mean(walk_ms))
-    graph_avg = float(np.mean(graph_ms))
-    seed_avg = float(np.mean(seed_ms))
-    seed_probes = int(batch.sizes().seed_probes)
+        batch.run(deliver & ~kmlib.KM_RUN_HIPGRAPH, st0)
+        batch.wait_result()
+        tm.append(batch.timings())
+    tm = np.mean(np.array(tm), axis=0)
+    walk_avg, graph_avg, _tot, seed_avg, pack_avg, dfs_avg, outk_avg, d2h_avg = (float(x) for x in tm)
 
-    # ---- result fetch (D2H + host reorganisation), reported beside the kernel rate ----------
+    # ---- result fetch through the copying API (numpy arrays, node k-mers rebuilt), for scale
     t_f = time.perf_counter()
     res = batch.fetch()
     fetch_s = time.perf_counter() - t_f
+    del res
 
-    # ---- end to end through the drop-in host path: strings -> GPU -> TSV rows -----------
+    # ---- BASELINE config 4 proper: 10 000 targets sharded over the N GPUs ----------------------
+    strong = None
+    if world > 1:
+        Ts = T // world
+        offs_s = (np.arange(Ts + 1, dtype=np.uint64) * np.uint64(args.length))
+        for q in range(n_fl):
+            lo = set_ids[q] * T + rank * Ts
+            batches[q].set_targets_dev(bases_all[lo:lo + Ts].data_ptr(), offs_s, stream)
+        torch.cuda.synchronize()
+        pipeline(n_fl, deliver, True)
+        dts = timed(deliver, True)
+        strong = {"targets_total": Ts * world, "targets_per_gpu": Ts, "ms_per_step": dts / args.steps * 1e3,
+                  "value": Ts * world / (dts / args.steps), "unit": "targets/s", "scaling": "strong"}
+        for q in range(n_fl):
+            batches[q].set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
+
+    # ---- end to end through the drop-in host path: strings -> GPU -> TSV rows -----------------
     e2e = None
     if rank == 0 and args.e2e > 0 and not args.only_step:
         from km_amd import kmer as km, report
@@ -264,18 +410,13 @@ def main():
         jf = Jellyfish("synthetic.jf", cutoff=0.05, n_cutoff=5, device=local_rank, db=db)
         finder = BatchFinder(jf)
         finder.rows(tg[:64])                                     # workspace allocation, first launch
+        finder.rows(tg)
         t_e = time.perf_counter()
         n_rows = sum(len(r) for r in finder.rows(tg))            # native reporting (km_report_rows)
         e2e = {"targets": n_e, "rows": n_rows, "seconds": time.perf_counter() - t_e}
         e2e["targets_per_s"] = n_e / e2e["seconds"]
-        t_e = time.perf_counter()
-        n_py = 0
-        for res_t in finder.analyse(tg[:min(n_e, 1000)]):        # the Python restatement, for scale
-            n_py += len(report.target_rows(res_t, jf.filename))
-        e2e["python_report_targets_per_s"] = min(n_e, 1000) / (time.perf_counter() - t_e)
 
-    # ---- `.jf` ingestion: the same records as a real binary/sorted file, host
-    #      reader + upload against the direct file -> HBM path
+    # ---- `.jf` ingestion -------------------------------------------------------
     ingest = None
     if rank == 0 and not args.only_step and args.ingest:
         import tempfile
@@ -304,8 +445,7 @@ def main():
                   "host_reader_parse_s": t_parse, "host_reader_plus_upload_s": t_host,
                   "direct_file_to_table_s": t_direct, "direct_GBs": size / t_direct / 1e9}
 
-    # ---- probe kernels alone (rows A2 / A3): Jellyfish.query and get_child for a resident
-    #      array of stored k-mers in random order; 12 resp. 48 algorithmic bytes per element
+    # ---- probe kernels alone (rows A2 / A3) ----------------------------------------------------
     probe = None
     if rank == 0 and d_probe is not None and not args.only_step:
         d_out = torch.empty(n_probe, dtype=torch.int32, device=dev)
@@ -334,7 +474,7 @@ def main():
         assert int((d_out == 0).sum().item()) == 0        # every stored k-mer is found
         del d_out, d_mask, d_c4
 
-    # ---- BASELINE config 2: latency of ONE target (FLT3-ITD, 75-nt ITD, walk depth 65) ----
+    # ---- BASELINE config 2: latency of ONE target (FLT3-ITD, 75-nt ITD, walk depth 65) --------
     single = None
     fix_fa = os.path.join(ROOT, "tests", "data", "catalog", "GRCh38", "FLT3-ITD_exons_13-15.fa")
     fix_db = os.path.join(ROOT, "tests", "data", "jf", "03H116_ITD.jf")
@@ -352,38 +492,25 @@ def main():
             r1 = f1.run_raw([seq1])
             lat.append((time.perf_counter() - t_s) * 1e3)
         single = {"target": "FLT3-ITD_exons_13-15 x 03H116_ITD.jf", "median_ms": float(np.median(lat)),
-                  "includes": "H2D of the target, 5 kernels, D2H of nodes and paths",
+                  "includes": "H2D of the target, kernels, delivery, D2H of nodes and paths",
                   "nodes": int(r1["node_off"][1]), "paths": int(r1["path_off"][1]),
                   "logical_probes": int(r1["probes"][0])}
 
-    if args.check and rank == 0:
-        from km_amd import kmer as km
-        from oracle import km_oracle as ko
-        nr = case["n_real"]
-        cpu = ko.KmerDB(None, 0.05, 5, records={"k": K, "canonical": True,
-                                                "keys": case["keys"][:nr], "counts": case["counts"][:nr]})
-        for t in range(0, T, max(1, T // 50)):
-            want = ko.analyse_target(km.decode(case["targets"][t]), "t", cpu)
-            a, e = int(res["node_off"][t]), int(res["node_off"][t + 1])
-            assert [km.unpack(x, K) for x in res["node_kmer"][a:e]] == want["kmers"], t
-            assert res["node_count"][a:e].tolist() == want["counts"], t
-            pa, pe = int(res["path_off"][t]), int(res["path_off"][t + 1])
-            assert [kmlib.expand_path(res, p).tolist() for p in range(pa, pe)] == \
-                [list(p) for p in want["paths"]], t
-        log("check ok")
-
+    rc = 0
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * T / (dt / args.steps)
-        # roofline of the dominant kernel (k_seed: ~89 % of all logical probes), timed by its
-        # own HIP events on the launch stream
-        achieved = seed_probes * BYTES_PER_PROBE / (seed_avg * 1e-3) / 1e9
-        walk_achieved = probes_per_step * BYTES_PER_PROBE / (walk_avg * 1e-3) / 1e9
+        ms_kernel = dt_kernel / args.steps * 1e3
+        gb = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+        alg_walk = probes_per_step * BYTES_PER_PROBE
+        alg_seed = seed_probes * BYTES_PER_PROBE
+        alg_dfs = (probes_per_step - seed_probes) * BYTES_PER_PROBE
+        walk_achieved = gb(alg_walk, walk_avg)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_seed_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("walk_stage_hbm_bytes_per_step")
             except Exception:
                 traffic = None
         out = {
@@ -403,39 +530,63 @@ def main():
                                    % (T, args.length, round(n_rec / 1e6)),
                        "targets_per_gpu": T, "target_len": args.length, "k": K,
                        "table_keys": n_rec, "table_bytes": int(info.table_bytes),
+                       "table_bytes_per_kmer": float(info.table_bytes) / max(1, n_rec),
+                       "table_max_probe": int(info.max_probe),
                        "params": "-c 5 -p 0.05 -s 500 -b 10 -n 10000",
-                       "parallelism": "target-sharded x%d, table replicated (1 RCCL broadcast)" % world},
+                       "stages": both_names + " + result delivery (device compaction, D2H to pinned host memory)",
+                       "distinct_target_sets": n_fl,
+                       "parallelism": "target-sharded x%d, table replicated (records broadcast once over RCCL)" % world},
+            "value_includes": "k_pack, k_seed, k_dfs, k_graph_pure, k_graph, k_out_scan, k_out_pack, D2H of every "
+                              "node count, walk-discovered k-mer, path and status into pinned host memory",
             "gprobes_per_s": world * probes_per_step / (dt / args.steps) / 1e9,
+            "kernel_only": {"value": world * T / (dt_kernel / args.steps), "ms_per_step": ms_kernel,
+                            "note": "same steps without result delivery (results left in HBM)"},
+            "delivered_bytes_per_step": out_bytes,
+            "d2h_GBs_inside_pipeline": gb(out_bytes, ms_per_step),
             "logical_probes_per_step": probes_per_step,
             "table_fetches_per_step": fetches_per_step,
-            "targets_in_large_tier": int(sizes.n_big_tier), "targets_flagged": int(sizes.n_flagged),
-            "kernel_ms": {"walk": walk_avg, "k_seed": seed_avg, "graph": graph_avg},
+            "targets_in_large_tier": int(sizes[0].n_big_tier), "targets_flagged": int(sizes[0].n_flagged),
+            "kernel_ms": {"walk": walk_avg, "k_pack": pack_avg, "k_seed": seed_avg, "k_dfs": dfs_avg,
+                          "graph": graph_avg, "deliver_kernels": outk_avg, "d2h_copy": d2h_avg,
+                          "note": "one batch at a time, HIP events on the launch stream"},
             "batches_in_flight": n_fl,
             "hipgraph_replay": bool(args.hipgraph),
             "ms_per_step_unpipelined": serial_ms,
-            "result_fetch_ms": fetch_s * 1e3,
+            "result_fetch_ms": outk_avg + d2h_avg,
+            "result_fetch_copying_api_ms": fetch_s * 1e3,
+            "oracle_check": check,
+            "config4_strong": strong,
             "end_to_end_host_path": e2e,
             "single_target_latency": single,
             "probe_kernels": probe,
+            "d2d_copy_GBs": d2d,
             "setup_s": {"generate": t_gen, "h2d_broadcast": t_bcast, "table_build": t_build},
             "jf_ingestion": ingest,
-            "roofline": {"bound": "hbm", "kernel": "k_seed", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": seed_probes * BYTES_PER_PROBE,
-                         "logical_probes_per_launch": seed_probes,
-                         "avg_launch_ms": seed_avg,
-                         "avg_launch_ms_inside_pipelined_region": seed_pipelined_ms,
-                         "walk_stage_achieved_GBs": walk_achieved},
+            # achieved = logical probes x 12 B / walk-stage time
+            "roofline": {"bound": "hbm", "kernel": "walk stage (k_pack + k_seed + k_dfs)",
+                         "achieved": walk_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": walk_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_walk,
+                         "logical_probes_per_launch": probes_per_step,
+                         "avg_launch_ms": walk_avg,
+                         "measured_copy_peak_GBs": d2d,
+                         "per_kernel": {
+                             "k_seed": {"achieved": gb(alg_seed, seed_avg), "frac": gb(alg_seed, seed_avg) / HBM_PEAK_GBS,
+                                        "avg_launch_ms": seed_avg, "algorithmic_bytes": alg_seed},
+                             "k_dfs": {"achieved": gb(alg_dfs, dfs_avg), "frac": gb(alg_dfs, dfs_avg) / HBM_PEAK_GBS,
+                                       "avg_launch_ms": dfs_avg, "algorithmic_bytes": alg_dfs},
+                             "whole_step_pipelined": {"achieved": gb(alg_walk, ms_per_step),
+                                                      "frac": gb(alg_walk, ms_per_step) / HBM_PEAK_GBS}}},
+            "cpu_baseline": cpu,
         }
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(case, min(args.cpu_sample, T), K)
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+        if check is not None and not check["ok"]:
+            log("ORACLE CHECK FAILED:", check)
+            rc = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

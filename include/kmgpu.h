@@ -87,10 +87,15 @@ typedef struct {
   uint32_t n_big_tier;     /* targets that needed the large-workspace pass     */
   uint32_t n_flagged;      /* targets with at least one non-trivial seed       */
   uint64_t seed_probes;    /* logical probes answered by the k_seed kernel     */
+  uint64_t n_extra;        /* walk-discovered nodes over all targets (n_nodes minus the targets' own k-mers) */
 } km_batch_sizes_t;
 
-/* Host-side result arrays, all caller-allocated (numpy).  Any pointer may be
- * NULL to skip that output.  Sizes come from km_batch_sizes().
+/* Host-side result arrays.  km_batch_fetch() fills caller-allocated arrays (numpy; any
+ * pointer may be NULL to skip that output; sizes come from km_batch_sizes());
+ * km_batch_result() instead points them into the batch's pinned delivery buffer (no copy;
+ * node_kmer is NULL there: a target's own k-mers are not shipped back to the caller who
+ * supplied them, node i < n_ref is the k-mer at base i of the target, and the
+ * walk-discovered nodes n_ref.. are in extra_kmer).
  *
  * Node order per target (canonical order): the target's own
  * k-mers in target order (node i == k-mer at position i), then walk-discovered
@@ -117,6 +122,9 @@ typedef struct {
   uint32_t* path_len;      /* [n_paths]     nodes on the path                           */
   uint32_t* path_min_cov;  /* [n_paths]     min count along the path
                                             (km/utils/MutationFinder.py:639,802)        */
+  uint64_t* extra_off;     /* [n_targets+1] CSR offsets into extra_kmer
+                                            (extra_off[t+1]-extra_off[t] == nodes of t - n_ref[t]) */
+  uint64_t* extra_kmer;    /* [n_extra]     packed k-mers of the walk-discovered nodes     */
 } km_batch_out_t;
 
 /* ---- database: replaces Jellyfish.__init__ (km/utils/Jellyfish.py:23-45) and
@@ -182,16 +190,29 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
  * launch afterwards (until the targets change).  Per-kernel HIP-event timings are not
  * available for replayed steps. */
 #define KM_RUN_HIPGRAPH 4
+/* OR into `stages`: also enqueue result delivery behind the kernels, on the same stream — the
+ * results are compacted on the device into their final layout (CSR, paths sorted) and cross
+ * PCIe with one asynchronous copy into the batch's pinned buffer; km_batch_result() then only
+ * waits for that copy.  Without this flag km_batch_result() / km_batch_fetch() deliver on
+ * demand. */
+#define KM_RUN_DELIVER 8
 /* Launch the kernels asynchronously on `stream` (no host synchronisation unless
  * a target overflows the fast tier, in which case the large-tier pass needs one). */
 int km_batch_run(km_batch_t* b, int stages, void* stream);
 int km_batch_sync(km_batch_t* b);
 int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* sizes);
 int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
+/* Zero-copy variant: waits for the delivery of the last run (finishing, if some target needed
+ * it, the large-workspace tier first) and points `view` into the batch's pinned host buffer;
+ * the arrays stay valid until the next km_batch_run / km_batch_set_targets on this batch.
+ * Either output may be NULL.  This is what `km find_mutation` needs per target
+ * (km/tools/find_mutation.py:49-58) and what km_report_rows consumes. */
+int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes);
 /* Durations (ms) of the last run measured with HIP events on the launch stream:
- * [0] walk stage (k_pack + k_seed + k_dfs), [1] graph stage, [2] whole run,
- * [3] the k_seed kernel alone. */
-int km_batch_timings(km_batch_t* b, float* ms4);
+ * [0] walk stage (k_pack + k_seed + k_dfs), [1] graph stage, [2] walk + graph,
+ * [3] k_seed, [4] k_pack, [5] k_dfs, [6] the delivery kernels (k_out_scan + k_out_pack),
+ * [7] the device-to-host copy ([6], [7]: 0 unless the run carried KM_RUN_DELIVER). */
+int km_batch_timings(km_batch_t* b, float* ms8);
 
 /* ---- host reporting: replaces, for all targets of a fetched batch at once, the per-target
  *      tail of km/tools/find_mutation.py:53-58 — MutationFinder.graph_analysis' naming and
@@ -205,7 +226,9 @@ typedef struct {
   const char* db_name;           /* the Database column                                       */
   int32_t k;
   int32_t reserved;
-  const km_batch_out_t* res;     /* arrays filled by km_batch_fetch (all of them)             */
+  const km_batch_out_t* res;     /* arrays of km_batch_fetch or km_batch_result: everything but
+                                    aux / probes / path_len; node_kmer may be NULL when
+                                    extra_off / extra_kmer are given                          */
 } km_report_in_t;
 /* text: the TSV rows of every KM_T_OK target, rows of one target separated by '\n';
  * row_off[t] .. row_off[t+1] is the block of target t (empty for other statuses);

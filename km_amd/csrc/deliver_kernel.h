@@ -1,0 +1,280 @@
+// deliver_kernel.h — result delivery: the walk / path-search outputs of a whole batch are
+// compacted ON THE DEVICE into one contiguous buffer in its final host layout, which then
+// crosses PCIe with a single asynchronous copy into pinned memory (kmgpu.hip: enqueue_deliver).
+//
+// What the reference hands on per target (km/tools/find_mutation.py:49-58 -> MutationFinder's
+// kmer / counts lists, km/utils/MutationFinder.py:122-124, and the paths of
+// km/utils/Graph.py:220-240) becomes, for all targets of the batch:
+//
+//   region A (offsets known on the host from n_targets alone)
+//     totals[OT_WORDS]                       sizes of the tail arrays + batch statistics
+//     status[n] n_ref[n] probes[n]           per target
+//     node_off[n+1] extra_off[n+1] path_off[n+1]     CSR offsets
+//   tail (sub-offsets in totals[], every array 16-byte aligned)
+//     node_count[n_nodes]     counts of every node, target k-mers first          (CSR node_off)
+//     extra_kmer[n_extra]     packed k-mers of the walk-discovered nodes only    (CSR extra_off)
+//                             — a target's own k-mers are not shipped: node i < n_ref is the
+//                             k-mer at base i of the target the caller already holds
+//     path_len[n_paths] path_min_cov[n_paths] run_off[n_paths+1]                 (CSR path_off)
+//     run_start[n_runs] run_len[n_runs]      paths, run-length encoded            (CSR run_off)
+//
+// Paths of one target are sorted by their node-index sequence here (the canonical order of
+// DESIGN.md §2), nodes carry no per-target slack, nothing is reorganised on the host.
+//
+//  k_out_scan  one block: per-target sizes -> exclusive scans -> offsets, totals, statistics
+//  k_out_pack  one wave per target: copies counts / extra k-mers, ranks and emits the paths
+#pragma once
+#include "device_common.h"
+#include "graph_kernel.h"
+#include "walk_kernel.h"
+
+namespace kmd {
+
+enum {
+  OT_N_NODES = 0, OT_N_EXTRA, OT_N_PATHS, OT_N_RUNS, OT_TAIL_BYTES,
+  OT_NEEDS_HOST,        // bit 0: some target needs the large tier / the path pools overflowed
+                        // bit 1: the tail does not fit the delivery buffer (nothing was packed)
+  OT_OFF_COUNT, OT_OFF_EXTRA, OT_OFF_PLEN, OT_OFF_PMIN, OT_OFF_RUNOFF, OT_OFF_RSTART, OT_OFF_RLEN,
+  OT_PROBES, OT_FETCHES, OT_SEED_PROBES, OT_N_FLAGGED, OT_SERIAL,
+  OT_WORDS = 32
+};
+
+constexpr uint32_t OUT_SCAN_THREADS = 1024;
+
+struct OutArgs {
+  uint32_t n_targets;
+  uint32_t ran_graph;
+  unsigned long long serial;           // stamped into totals[OT_SERIAL]: which run this delivery belongs to
+  // walk / graph results
+  const uint32_t* status;
+  const uint32_t* g_status;
+  const uint32_t* n_nodes;
+  const uint32_t* n_ref;
+  const uint32_t* t_npaths;
+  const uint32_t* t_pathbase;
+  const uint32_t* t_nruns;
+  const unsigned long long* probes;
+  const unsigned long long* dfs_probes;
+  const unsigned long long* fetches;
+  const unsigned long long* pool_overflow;   // path / run pools exhausted (graph kernels)
+  const uint32_t* n_flagged;
+  const uint64_t* node_base;
+  const uint64_t* node_kmer;
+  const uint32_t* node_cnt;
+  const uint64_t* p_runbase;
+  const uint32_t* p_nruns;
+  const uint32_t* p_len;
+  const uint32_t* p_mincov;
+  const uint32_t* r_start;
+  const uint32_t* r_len;
+  // scratch
+  uint64_t* run_tbase;                 // [n] first output run of each target
+  unsigned long long* psort;           // [path pool] (source path << 32 | runs) in sorted order
+  // delivery buffer
+  unsigned long long* totals;
+  uint32_t* o_status;
+  uint32_t* o_nref;
+  uint64_t* o_probes;
+  uint64_t* o_node_off;
+  uint64_t* o_extra_off;
+  uint32_t* o_path_off;
+  unsigned char* tail;
+  uint64_t tail_cap;
+};
+
+__host__ __device__ inline uint64_t out_align(uint64_t v) { return (v + 15) & ~15ull; }
+
+struct OutCounts { uint64_t nodes, extra, paths, runs; };
+
+__device__ inline OutCounts out_counts_of(const OutArgs& a, uint32_t t, uint32_t* needs, uint32_t* st_out) {
+  const uint32_t st = a.status[t];
+  const uint32_t gs = a.ran_graph ? a.g_status[t] : T_OK;
+  OutCounts c = {0, 0, 0, 0};
+  if (st == T_NEEDS_BIG || (st == T_OK && gs == T_NEEDS_BIG)) *needs = 1;
+  if (st == T_OK || st == T_NODE_LIMIT) {
+    c.nodes = a.n_nodes[t];
+    const uint32_t nr = a.n_ref[t];
+    c.extra = c.nodes > nr ? c.nodes - nr : 0;
+  }
+  if (a.ran_graph && st == T_OK && gs == T_OK) {
+    c.paths = a.t_npaths[t];
+    c.runs = a.t_nruns[t];
+  }
+  *st_out = (st == T_OK && gs != T_OK) ? T_INTERNAL : st;
+  return c;
+}
+
+__global__ __launch_bounds__(OUT_SCAN_THREADS) void k_out_scan(OutArgs a) {
+  __shared__ unsigned long long part[4][OUT_SCAN_THREADS / 64];
+  __shared__ unsigned long long stat[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n = a.n_targets;
+  const uint32_t per = (n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS;
+  const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+  if (tid < 4) stat[tid] = 0;
+  __syncthreads();
+  // pass 1: this thread's totals
+  unsigned long long s[4] = {0, 0, 0, 0};
+  unsigned long long probes = 0, fetches = 0, seedp = 0;
+  uint32_t needs = 0;
+  for (uint32_t t = lo; t < hi; ++t) {
+    uint32_t st;
+    const OutCounts c = out_counts_of(a, t, &needs, &st);
+    s[0] += c.nodes; s[1] += c.extra; s[2] += c.paths; s[3] += c.runs;
+    const unsigned long long sp = a.probes[t], dp = a.dfs_probes[t];
+    seedp += sp; probes += sp + dp; fetches += a.fetches[t];
+    a.o_status[t] = st;
+    a.o_nref[t] = a.n_ref[t];
+    a.o_probes[t] = sp + dp;
+  }
+  // exclusive scan of the four sums over the block: within the wave, then across the waves
+  unsigned long long ex[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned long long v = s[q];
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long u = __shfl_up(v, o);
+      if ((int)lane >= o) v += u;
+    }
+    if (lane == 63) part[q][wave] = v;
+    ex[q] = v - s[q];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    probes += __shfl_xor(probes, o); fetches += __shfl_xor(fetches, o); seedp += __shfl_xor(seedp, o);
+    needs |= __shfl_xor(needs, o);
+  }
+  if (lane == 0) {
+    atomicAdd(&stat[0], probes); atomicAdd(&stat[1], fetches); atomicAdd(&stat[2], seedp);
+    if (needs) atomicOr(&stat[3], 1ull);
+  }
+  __syncthreads();
+  unsigned long long tot[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned long long before = 0, all = 0;
+    for (uint32_t w = 0; w < OUT_SCAN_THREADS / 64; ++w) {
+      const unsigned long long v = part[q][w];
+      if (w < wave) before += v;
+      all += v;
+    }
+    ex[q] += before;
+    tot[q] = all;
+  }
+  // pass 2: offsets
+  unsigned long long c0 = ex[0], c1 = ex[1], c2 = ex[2], c3 = ex[3];
+  for (uint32_t t = lo; t < hi; ++t) {
+    uint32_t st, nd = 0;
+    const OutCounts c = out_counts_of(a, t, &nd, &st);
+    a.o_node_off[t] = c0; a.o_extra_off[t] = c1; a.o_path_off[t] = (uint32_t)c2; a.run_tbase[t] = c3;
+    c0 += c.nodes; c1 += c.extra; c2 += c.paths; c3 += c.runs;
+  }
+  if (tid == 0) {
+    a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
+    unsigned long long* T = a.totals;
+    uint64_t o = 0;
+    T[OT_N_NODES] = tot[0]; T[OT_N_EXTRA] = tot[1]; T[OT_N_PATHS] = tot[2]; T[OT_N_RUNS] = tot[3];
+    T[OT_OFF_COUNT] = o;  o = out_align(o + 4 * tot[0]);
+    T[OT_OFF_EXTRA] = o;  o = out_align(o + 8 * tot[1]);
+    T[OT_OFF_PLEN] = o;   o = out_align(o + 4 * tot[2]);
+    T[OT_OFF_PMIN] = o;   o = out_align(o + 4 * tot[2]);
+    T[OT_OFF_RUNOFF] = o; o = out_align(o + 8 * (tot[2] + 1));
+    T[OT_OFF_RSTART] = o; o = out_align(o + 4 * tot[3]);
+    T[OT_OFF_RLEN] = o;   o = out_align(o + 4 * tot[3]);
+    T[OT_TAIL_BYTES] = o;
+    unsigned long long nh = stat[3];
+    if (a.ran_graph && *a.pool_overflow) nh |= 1ull;
+    if (tot[2] >= (1ull << 32)) nh |= 1ull;           // path_off is 32-bit: the host splits such batches
+    if (o > a.tail_cap) nh |= 2ull;
+    T[OT_NEEDS_HOST] = nh;
+    T[OT_PROBES] = stat[0]; T[OT_FETCHES] = stat[1]; T[OT_SEED_PROBES] = stat[2];
+    T[OT_N_FLAGGED] = *a.n_flagged;
+    T[OT_SERIAL] = a.serial;
+    for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) T[q] = 0;
+  }
+}
+
+// lexicographic order of two run-length encoded index sequences
+__device__ inline bool rle_less(const uint32_t* sa, const uint32_t* la, uint32_t na,
+                                const uint32_t* sb, const uint32_t* lb, uint32_t nb) {
+  uint32_t ia = 0, ib = 0, oa = 0, ob = 0;
+  while (ia < na && ib < nb) {
+    const uint32_t va = sa[ia] + oa, vb = sb[ib] + ob;
+    if (va != vb) return va < vb;
+    const uint32_t ra = la[ia] - oa, rb = lb[ib] - ob;
+    const uint32_t step = ra < rb ? ra : rb;
+    oa += step; ob += step;
+    if (oa == la[ia]) { ++ia; oa = 0; }
+    if (ob == lb[ib]) { ++ib; ob = 0; }
+  }
+  return ia == na && ib < nb;
+}
+
+__global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
+  const uint32_t t = blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long* T = a.totals;
+  if (T[OT_NEEDS_HOST]) return;          // the host finishes the batch and delivers again
+  const uint64_t n0 = a.o_node_off[t], n1 = a.o_node_off[t + 1];
+  const uint64_t e0 = a.o_extra_off[t], e1 = a.o_extra_off[t + 1];
+  const uint32_t p0 = a.o_path_off[t], p1 = a.o_path_off[t + 1];
+  const uint64_t nb = a.node_base[t];
+  uint32_t* o_cnt = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_COUNT]);
+  uint64_t* o_ext = reinterpret_cast<uint64_t*>(a.tail + T[OT_OFF_EXTRA]);
+  uint32_t* o_plen = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_PLEN]);
+  uint32_t* o_pmin = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_PMIN]);
+  uint64_t* o_roff = reinterpret_cast<uint64_t*>(a.tail + T[OT_OFF_RUNOFF]);
+  uint32_t* o_rs = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_RSTART]);
+  uint32_t* o_rl = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_RLEN]);
+  // ---- nodes
+  const uint32_t nn = (uint32_t)(n1 - n0), ne = (uint32_t)(e1 - e0);
+  {
+    const uint32_t* src = a.node_cnt + nb;
+    uint32_t* dst = o_cnt + n0;
+    for (uint32_t i = lane; i < nn; i += 64) dst[i] = src[i];
+  }
+  if (ne) {
+    const uint64_t* src = a.node_kmer + nb + (nn - ne);
+    uint64_t* dst = o_ext + e0;
+    for (uint32_t i = lane; i < ne; i += 64) dst[i] = src[i];
+  }
+  if (t + 1 == a.n_targets && lane == 0) o_roff[T[OT_N_PATHS]] = T[OT_N_RUNS];
+  // ---- paths, sorted by index sequence
+  const uint32_t np = p1 - p0;
+  if (np == 0) return;
+  const uint32_t pb = a.t_pathbase[t];
+  uint64_t cur = a.run_tbase[t];
+  if (np == 1) {
+    const uint32_t nr = a.p_nruns[pb];
+    const uint64_t rb = a.p_runbase[pb];
+    if (lane == 0) { o_plen[p0] = a.p_len[pb]; o_pmin[p0] = a.p_mincov[pb]; o_roff[p0] = cur; }
+    for (uint32_t q = lane; q < nr; q += 64) { o_rs[cur + q] = a.r_start[rb + q]; o_rl[cur + q] = a.r_len[rb + q]; }
+    return;
+  }
+  for (uint32_t i = lane; i < np; i += 64) {
+    const uint32_t ni = a.p_nruns[pb + i];
+    const uint32_t* si = a.r_start + a.p_runbase[pb + i];
+    const uint32_t* li = a.r_len + a.p_runbase[pb + i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < np; ++j) {
+      if (j == i) continue;
+      const uint32_t nj = a.p_nruns[pb + j];
+      const uint32_t* sj = a.r_start + a.p_runbase[pb + j];
+      const uint32_t* lj = a.r_len + a.p_runbase[pb + j];
+      if (rle_less(sj, lj, nj, si, li, ni) || (j < i && !rle_less(si, li, ni, sj, lj, nj))) ++rank;
+    }
+    a.psort[pb + rank] = ((unsigned long long)i << 32) | ni;
+    o_plen[p0 + rank] = a.p_len[pb + i];
+    o_pmin[p0 + rank] = a.p_mincov[pb + i];
+  }
+  __syncthreads();                       // psort written by other lanes (single-wave workgroup)
+  for (uint32_t r = 0; r < np; ++r) {
+    const unsigned long long e = a.psort[pb + r];
+    const uint32_t i = (uint32_t)(e >> 32), nr = (uint32_t)e;
+    const uint64_t rb = a.p_runbase[pb + i];
+    if (lane == 0) o_roff[p0 + r] = cur;
+    for (uint32_t q = lane; q < nr; q += 64) { o_rs[cur + q] = a.r_start[rb + q]; o_rl[cur + q] = a.r_len[rb + q]; }
+    cur += nr;
+  }
+}
+
+}  // namespace kmd

@@ -201,6 +201,15 @@ __host__ __device__ inline Key make_key(const TableView& t, uint64_t P) {
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
+// k-mer i of a 2-bit packed target (32 bases per word, first base most significant; the
+// packed form carries one extra zero word, so words[w + 1] is always readable)
+__device__ inline uint64_t kmer_from_words(const uint64_t* words, uint32_t i, int k) {
+  const uint32_t w = i >> 5, sh = (i & 31) * 2;
+  const uint64_t hi = words[w], lo = words[w + 1];
+  const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+  return x >> (64 - 2 * k);
+}
+
 // The same key for a wave-uniform P with the windows spread over the lanes (k_dfs: one
 // lookup per walk step, latency matters).  Every lane returns the full key.
 __device__ inline Key make_key_wave(const TableView& t, uint64_t P) {

@@ -55,9 +55,13 @@ struct GraphArgs {
   uint64_t pmask;
   const uint32_t* tids;      // BIG: targets to run; nullptr = blockIdx.x
   uint32_t n_targets;
-  const uint64_t* node_kmer;
+  const uint64_t* node_kmer;   // walk-discovered nodes only (index >= n_ref); the target's own
+                               // k-mers are read from its packed words
   const uint32_t* node_cnt;
   const uint64_t* node_base;
+  const uint64_t* packed;      // 2-bit packed targets (k_pack)
+  const uint64_t* woff;        // word offsets into `packed`
+  uint32_t words_cap;          // packed words staged per target (>= (max_len + 31) / 32 + 1)
   const uint32_t* n_nodes;
   const uint32_t* n_ref;
   uint32_t* status;          // T_REPEAT is raised here (duplicate k-mer in the target)
@@ -69,6 +73,7 @@ struct GraphArgs {
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
   uint32_t* t_pathbase;      // per target: first path record
+  uint32_t* t_nruns;         // per target: run records over all its paths
   // Pools are split into POOL_GROUPS equal regions (group = target & 63) so that the
   // bump-allocation atomics of different targets rarely share an address.
   // counters[g*16+0] paths used in group g, [g*16+1] runs used, counters[64*16] overflow flag
@@ -99,12 +104,14 @@ __host__ __device__ inline uint64_t graph_region_a(uint32_t ncap, uint32_t hcap)
 }
 
 template <typename idx_t>
-__host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap) {
+__host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap, uint32_t words_cap) {
   uint64_t b = graph_region_a<idx_t>(ncap, hcap);
+
   b += (((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull;  // succ, pred
   b += (uint64_t)((ncap + 31) / 32) * 4 * 3;                  // link, inq (forward / backward) bits
   b += (uint64_t)((4 * (uint64_t)ncap + 2 + 31) / 32) * 4;    // removed bits
   b += 32;                                                    // scalars
+  b += 8 + (uint64_t)words_cap * 8;                           // packed target (8-byte aligned)
   return (b + 15) & ~15ull;
 }
 
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
   if (h_status != T_OK) {
-    if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
   }
   if (h_tflag) return;                         // k_graph handles it once k_dfs is done
@@ -134,8 +141,18 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     if (tid == 0) a.need_full[t] = 1;
     return;
   }
-  const uint64_t* nk = a.node_kmer + nb;
   const uint32_t* ncnt = a.node_cnt + nb;
+  // the packed target: n_ref + k - 1 bases, (L + 31) / 32 + 1 words (the last one zero)
+  const uint32_t nwords = (n_ref + (uint32_t)a.k - 1 + 31) >> 5;
+  uint64_t* words = reinterpret_cast<uint64_t*>(smem + (uint64_t)hcap * 4);
+  if (nwords + 1 > a.words_cap) {
+    if (tid == 0) a.need_full[t] = 1;
+    return;
+  }
+  {
+    const uint64_t* src = a.packed + a.woff[t];
+    for (uint32_t w = tid; w <= nwords; w += NT) words[w] = src[w];
+  }
   // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of
   // the last) distinct?  A set of 32-bit FINGERPRINTS at load <= 1/4 answers it: equal
   // (k-1)-mers always meet (same fingerprint, same home); two different ones with the same
@@ -169,7 +186,8 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
       const uint32_t j = j0 + u * NT;
-      kk[u] = j < n_ref ? (nk[j] >> 2) : (j == n_ref ? (nk[n_ref - 1] & a.pmask) : 0);
+      kk[u] = j < n_ref ? (kmer_from_words(words, j, a.k) >> 2)
+                        : (j == n_ref ? (kmer_from_words(words, n_ref - 1, a.k) & a.pmask) : 0);
       cc[u] = j < n_ref ? ncnt[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -192,12 +210,12 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
     if (pl + 1 > pg_paths || rl + 1 > pg_runs) {
       atomicExch(a.counters + (uint64_t)POOL_GROUPS * POOL_CTR_STRIDE, 1ull);
-      a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
+      a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0;
     } else {
       const uint64_t pi = (uint64_t)pg * pg_paths + pl, ri = (uint64_t)pg * pg_runs + rl;
       a.r_start[ri] = 0; a.r_len[ri] = n_ref;
       a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
-      a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
+      a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi; a.t_nruns[t] = 1;
     }
     a.need_full[t] = 0;
     a.g_status[t] = T_OK;
@@ -234,19 +252,24 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
   if (h_status != T_OK) {
-    if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
   }
   if (a.use_need_full && !h_tflag && !h_need) return;   // answered by k_graph_pure
   const uint32_t n = m + 2, src = m, snk = m + 1;
   const uint32_t ncap = a.ncap, hcap = a.hcap;
   if (n > ncap || (uint64_t)3 * n > (uint64_t)2 * hcap || (!BIG && n >= 0xFFFFu)) {
-    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
   }
-  const uint64_t* nk = a.node_kmer + nb;
+  const uint64_t* nkx = a.node_kmer + nb;        // valid for indices >= n_ref only
   const uint32_t* ncnt = a.node_cnt + nb;
   const int k = a.k;
+  const uint32_t nwords = (n_ref + (uint32_t)k - 1 + 31) >> 5;
+  if (nwords + 1 > a.words_cap) {
+    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+    return;
+  }
 
   unsigned char* wsb;
   if constexpr (BIG) wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
@@ -275,6 +298,9 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   uint32_t* removed = inq_b + nbw;
   const uint32_t n_removed_words = (uint32_t)((4 * (uint64_t)ncap + 2 + 31) / 32);
   uint32_t* scal = removed + n_removed_words;      // [0] candidate count, [1] pool flag
+  // packed target, 8-byte aligned behind the scalars
+  uint64_t* words = reinterpret_cast<uint64_t*>(
+      wsb + (((uint64_t)(reinterpret_cast<unsigned char*>(scal + 8) - wsb) + 7) & ~7ull));
 
   const float INF = __int_as_float(0x7F800000);
   const float W_REF = 0.01f, W_ALT = 1.0f;
@@ -291,6 +317,12 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     uint4* q = reinterpret_cast<uint4*>(wsb);
     for (uint64_t x = tid; x < (uint64_t)hcap / 2; x += NT) q[x] = ones;      // hcap keys, 8 B each
   }
+  {
+    const uint64_t* srcw = a.packed + a.woff[t];
+    for (uint32_t w = tid; w <= nwords; w += NT) words[w] = srcw[w];
+  }
+  // node j's k-mer: the target's own k-mers come from its packed words
+  auto nk = [&](uint32_t j) -> uint64_t { return j < n_ref ? kmer_from_words(words, j, k) : nkx[j]; };
   for (uint32_t w = tid; w < nbw; w += NT) { link[w] = 0; inq[w] = 0; inq_b[w] = 0; }
   for (uint32_t w = tid; w < n_removed_words; w += NT) removed[w] = 0;
   if (tid < 8) scal[tid] = 0;
@@ -298,7 +330,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   uint32_t shared_prefix = 0;            // some other node has the same (k-1)-mer prefix
   for (uint32_t j = tid; j < m; j += NT) {
     bool wn;
-    const int s = set_insert_lane(pkeys, hcap, nk[j] >> 2, &wn);
+    const int s = set_insert_lane(pkeys, hcap, nk(j) >> 2, &wn);
     if (s < 0 || !wn) shared_prefix = 1;
   }
   __syncthreads();
@@ -311,7 +343,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   {
     uint32_t not_pure = shared_prefix | (m != n_ref ? 1u : 0u) | ((a.dbg != 0 && !keep_pure) ? 1u : 0u);
     if (tid == 0 && !not_pure) {
-      const uint64_t S = nk[m - 1] & a.pmask;
+      const uint64_t S = nk(m - 1) & a.pmask;
       uint32_t s = set_home(S, hcap);
       for (uint32_t step = 0; step < hcap; ++step) {
         const uint64_t kv = pkeys[s];
@@ -330,12 +362,12 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
           const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
           if (pl + 1 > pg_paths || rl + 1 > pg_runs) {
             atomicExch(ovf, 1ull);
-            a.t_npaths[t] = 0; a.t_pathbase[t] = 0;
+            a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0;
           } else {
             const uint64_t pi = (uint64_t)pg * pg_paths + pl, ri = (uint64_t)pg * pg_runs + rl;
             a.r_start[ri] = 0; a.r_len[ri] = n_ref;
             a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
-            a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi;
+            a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi; a.t_nruns[t] = 1;
           }
           a.g_status[t] = T_OK;
         }
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   {
     uint32_t dup = 0;
     for (uint32_t j = tid; j < m; j += NT) {
-      const uint64_t X = nk[j];
+      const uint64_t X = nk(j);
       const uint64_t P = X >> 2;
       uint32_t s = set_home(P, hcap);
       for (uint32_t step = 0; step < hcap; ++step) {
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     // a k-mer present twice (km/utils/common.py:55-59) shares one table entry: one of the
     // two nodes does not find its own index there
     for (uint32_t j = tid; j < m; j += NT) {
-      const uint64_t X = nk[j];
+      const uint64_t X = nk(j);
       const uint64_t P = X >> 2;
       uint32_t s = set_home(P, hcap);
       idx_t got = NONE;
@@ -380,14 +412,14 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
       if (got != (idx_t)j) dup = 1;
     }
     if (__syncthreads_or((int)dup)) {
-      if (tid == 0) { a.status[t] = T_REPEAT; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+      if (tid == 0) { a.status[t] = T_REPEAT; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
       return;
     }
   }
-  if (a.dbg == 1) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 1) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 2. adjacency: succ[4j+c] = node of kmer[j][1:]+c ; pred[4v+f] = j, f = first base of j
   for (uint32_t j = tid; j < m; j += NT) {
-    const uint64_t X = nk[j];
+    const uint64_t X = nk(j);
     const uint64_t S = X & a.pmask;
     const uint32_t fb = (uint32_t)(X >> (2 * (k - 1))) & 3u;
     uint32_t s = set_home(S, hcap);
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     }
   }
   __syncthreads();
-  if (a.dbg == 2) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 2) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 2b. link[j]: j -> j+1 is j's only out-edge and j+1's only in-edge ---------------
   for (uint32_t base = wave * 64; base < m; base += NT) {
     const uint32_t j = base + lane;
@@ -453,7 +485,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   for (uint32_t j = tid; j < n; j += NT) { dist_f[j] = INF; dist_b[j] = INF; }
   __syncthreads();
 
-  if (a.dbg == 3) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 3) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 3. exact distances -------------------------------------------------------------
   // the two passes are independent: wave 0 runs the forward one, wave 1 the backward one
   if (wave < 2) {
@@ -568,7 +600,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   }   // waves 0, 1
   __syncthreads();
 
-  if (a.dbg == 4) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 4) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 4. predecessor arrays by the local rule ------------------------------------
   for (uint32_t j = tid; j < n; j += NT) {
     {
@@ -627,7 +659,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   };
   auto is_removed = [&](uint32_t e) -> bool { return (removed[e >> 5] >> (e & 31)) & 1u; };
 
-  if (a.dbg == 5) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 5) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 5. strip reference edges (Graph.py:184-197) ---------------------------------
   // curs = nodes whose predecessor is the source; only node 0 has an edge from it.
   if (before[0] == (idx_t)src) {
@@ -658,7 +690,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   }
   __syncthreads();
 
-  if (a.dbg == 6) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 6) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 6. candidate edges and their unique representatives --------------------------
   const uint32_t n_edges = 4 * m + 2;
   for (uint32_t e = tid; e < n_edges; e += NT) {
@@ -687,11 +719,11 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   __syncthreads();
   const uint32_t n_cand = scal[0];
   if (n_cand > ccap) {
-    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
   }
 
-  if (a.dbg == 7) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; } return; }
+  if (a.dbg == 7) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 7. emit paths (caps stripped) as runs of consecutive node indices -------------
   // A path is walked chain by chain (wave-uniform): backwards from `a` along before[]
   // — inside a chain before[j] == j-1 — then forwards from `b` along after[].  Runs
@@ -785,7 +817,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   run_base = __shfl(run_base, 0);
   over = __shfl(over, 0);
   if (over) {        // pools exhausted: host enlarges them and reruns the stage
-    if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; }
+    if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
   }
   // pass 2: write runs, lengths and min coverage
@@ -819,6 +851,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     a.g_status[t] = T_OK;
     a.t_npaths[t] = n_cand;
     a.t_pathbase[t] = (uint32_t)path_base;
+    a.t_nruns[t] = total_runs;
   }
 }
 

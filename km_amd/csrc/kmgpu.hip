@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/kmgpu.h"
+#include "deliver_kernel.h"
 #include "device_common.h"
 #include "graph_kernel.h"
 #include "jf_reader.h"
@@ -600,6 +601,25 @@ struct DevBuf {
 
 constexpr uint32_t FAST_EXTRA = 160;          // walk-discovered nodes a fast-tier target may add
 constexpr uint32_t FAST_LDS_LIMIT = 64 * 1024;
+constexpr uint32_t FAST_BCAP_MAX = 512;       // branch frames the fast tier keeps in LDS
+constexpr uint32_t FAST_FCAP_MAX = 4096;      // stack frames per target in the fast tier's scratch
+
+// Region A of the delivery buffer (deliver_kernel.h): offsets from n_targets alone.
+struct OutLayout { uint64_t totals, status, n_ref, probes, node_off, extra_off, path_off, a_bytes; };
+OutLayout out_layout(uint32_t n) {
+  auto al = [](uint64_t v) { return (v + 63) & ~63ull; };
+  OutLayout L;
+  uint64_t o = 0;
+  L.totals = o;    o = al(o + 8ull * OT_WORDS);
+  L.status = o;    o = al(o + 4ull * n);
+  L.n_ref = o;     o = al(o + 4ull * n);
+  L.probes = o;    o = al(o + 8ull * n);
+  L.node_off = o;  o = al(o + 8ull * ((uint64_t)n + 1));
+  L.extra_off = o; o = al(o + 8ull * ((uint64_t)n + 1));
+  L.path_off = o;  o = al(o + 4ull * ((uint64_t)n + 1));
+  L.a_bytes = o;
+  return L;
+}
 
 }  // namespace
 
@@ -611,12 +631,10 @@ struct km_batch {
   int device = 0;
   uint32_t n_targets = 0;
   uint64_t total_bases = 0;
+  uint64_t total_ref = 0;
   uint32_t max_len = 0;
   bool ran_walk = false, ran_graph = false, synced = true;
   hipStream_t last_stream = nullptr;
-  // pinned staging for km_batch_fetch (node pools cross PCIe at DMA speed, no zero-filled vectors)
-  unsigned char* pin = nullptr;
-  uint64_t pin_cap = 0;
 
   // inputs
   DevBuf<uint8_t> d_bases;
@@ -632,14 +650,15 @@ struct km_batch {
   std::vector<uint32_t> h_item_off;
   std::vector<uint64_t> h_fw_off;
   uint32_t n_items = 0;
-  bool big_walk_done = false;
   int graph_mode = 0;                  // 1 = duplicate check only (walk stage run alone)
   // per-target
   DevBuf<uint64_t> d_node_base;
   DevBuf<uint32_t> d_node_cap;
-  std::vector<uint64_t> h_node_base;
-  std::vector<uint32_t> h_node_cap;
-  DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full;
+  std::vector<uint64_t> h_node_base, h_node_base0;   // ...0: the fast-tier layout of layout_targets
+  std::vector<uint32_t> h_node_cap, h_node_cap0;
+  uint64_t node_pool0 = 0;
+  bool layout_moved = false;           // the large tier re-homed some targets: restore before the next run
+  DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full, d_t_nruns;
   hipStream_t side = nullptr;          // overlaps k_graph_pure with k_dfs
   hipEvent_t ev_seed_done = nullptr, ev_pure_done = nullptr;       // eager fork / join
   hipEvent_t ev_cap_seed = nullptr, ev_cap_pure = nullptr;         // fork / join inside a captured step
@@ -653,13 +672,24 @@ struct km_batch {
   // node pools
   DevBuf<uint64_t> d_node_kmer;
   DevBuf<uint32_t> d_node_cnt;
-  uint64_t node_pool_used = 0;       // fast-tier part
+  uint64_t node_pool_used = 0;
   // path pools
   DevBuf<unsigned long long> d_counters;
   DevBuf<uint32_t> d_p_target, d_p_nruns, d_p_len, d_p_mincov, d_r_start, d_r_len;
   DevBuf<uint64_t> d_p_runbase;
   uint64_t path_pool = 0, run_pool = 0;
-  // big tier
+  // delivery (deliver_kernel.h): device buffer in its final host layout + its pinned host twin
+  DevBuf<uint64_t> d_run_tbase;
+  DevBuf<unsigned long long> d_psort;
+  unsigned char* d_out = nullptr;
+  unsigned char* h_out = nullptr;
+  uint64_t out_cap = 0;
+  hipEvent_t ev_out = nullptr;
+  bool deliver_pending = false, result_ready = false;
+  uint64_t copied_tail = 0, tail_guess = 0;
+  unsigned long long serial = 0;
+  std::vector<uint64_t> h_packed;     // km_batch_fetch: packed targets, when node_kmer is asked for
+  // large tier
   DevBuf<unsigned char> d_frames;     // fast-tier DFS stack frames, one slice per target
   DevBuf<unsigned long long> d_stamps; // diagnostics: k_seed time stamps (KM_SEED_STAMPS)
   DevBuf<float> d_tref;               // shared reference-chain distances
@@ -667,21 +697,39 @@ struct km_batch {
   DevBuf<unsigned char> d_big_ws;
   // host mirrors after sync
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
-  std::vector<uint64_t> h_probes, h_fetches;
-  std::vector<unsigned long long> h_dfs_probes;
   unsigned long long h_overflow = 0;
   uint32_t n_big = 0;
   // geometry of the last launch
-  bool fast_ok = true;
   WalkArgs wa{};
   GraphArgs ga{};
   uint32_t walk_lds = 0, graph_lds = 0;
   // timing
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  float ms[4] = {0, 0, 0, 0};
-  unsigned long long h_seed_probes = 0;
-  uint32_t h_nflagged = 0;
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool timed_deliver = false;
 };
+
+static uint64_t default_tail_bytes(const km_batch* b, uint64_t nodes, uint64_t extra) {
+  return out_align(4 * nodes) + out_align(8 * extra) + 2 * out_align(4 * b->path_pool) +
+         out_align(8 * (b->path_pool + 1)) + 2 * out_align(4 * b->run_pool) + 256;
+}
+
+// Delivery buffers: region A for max_targets + `tail_need` bytes of tail.
+static int ensure_out(km_batch* b, uint64_t tail_need) {
+  const uint64_t need = out_layout(b->max_targets).a_bytes + tail_need;
+  if (b->d_out && b->h_out && need <= b->out_cap) return KM_OK;
+  if (b->d_out) (void)hipFree(b->d_out);
+  if (b->h_out) (void)hipHostFree(b->h_out);
+  b->d_out = nullptr; b->h_out = nullptr; b->out_cap = 0;
+  const uint64_t cap = need + need / 8;
+  if (hipMalloc((void**)&b->d_out, cap) != hipSuccess) { b->d_out = nullptr; return fail(KM_E_NOMEM, "hipMalloc of the delivery buffer failed"); }
+  if (hipHostMalloc((void**)&b->h_out, cap, hipHostMallocDefault) != hipSuccess) {
+    b->h_out = nullptr;
+    return fail(KM_E_NOMEM, "pinned allocation of %llu bytes failed", (unsigned long long)cap);
+  }
+  b->out_cap = cap;
+  return KM_OK;
+}
 
 extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t max_targets,
                                uint64_t max_total_bases, km_batch_t** out) {
@@ -718,6 +766,8 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_npaths.alloc(max_targets));
   A(b->d_pathbase.alloc(max_targets));
   A(b->d_need_full.alloc(max_targets));
+  A(b->d_t_nruns.alloc(max_targets));
+  A(b->d_run_tbase.alloc((uint64_t)max_targets + 1));
   A(b->d_probes.alloc(max_targets));
   A(b->d_fetches.alloc(max_targets));
   const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA;
@@ -726,23 +776,31 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_counters.alloc(POOL_GROUPS * POOL_CTR_STRIDE + 16));
   b->path_pool = (((uint64_t)max_targets * 4 + 8192) / POOL_GROUPS + 1) * POOL_GROUPS;
   b->run_pool = (((uint64_t)max_targets * 16 + 32768) / POOL_GROUPS + 1) * POOL_GROUPS;
+  if (getenv("KM_TEST_SMALL_POOLS")) {         // tests: force the pool-overflow path of km_batch_sync
+    b->path_pool = 2 * POOL_GROUPS;
+    b->run_pool = 4 * POOL_GROUPS;
+  }
   A(b->d_p_target.alloc(b->path_pool));
   A(b->d_p_runbase.alloc(b->path_pool));
   A(b->d_p_nruns.alloc(b->path_pool));
   A(b->d_p_len.alloc(b->path_pool));
   A(b->d_p_mincov.alloc(b->path_pool));
+  A(b->d_psort.alloc(b->path_pool));
   A(b->d_r_start.alloc(b->run_pool));
   A(b->d_r_len.alloc(b->run_pool));
+  // the walk rarely adds more than a few nodes per target: the tail grows on demand
+  if (rc == KM_OK) rc = ensure_out(b, default_tail_bytes(b, max_total_bases + 16ull * max_targets, 16ull * max_targets));
   if (rc == KM_OK) {
     if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_seed_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_pure_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_cap_seed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_cap_pure, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&b->ev_cap_pure, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming) != hipSuccess)
       rc = fail(KM_E_HIP, "stream/event creation failed");
   }
   if (rc == KM_OK) {
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 7; ++i)
       if (hipEventCreate(&b->ev[i]) != hipSuccess) rc = fail(KM_E_HIP, "hipEventCreate failed");
   }
   if (rc != KM_OK) { km_batch_destroy(b); return rc; }
@@ -764,20 +822,25 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   drop_graph(b);
   b->d_bases.release(); b->d_toff.release(); b->d_woff.release(); b->d_packed.release();
   b->d_items.release(); b->d_item_off.release(); b->d_flagbits.release(); b->d_fw_off.release();
-  b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_dfs_probes.release(); b->d_node_base.release(); b->d_node_cap.release();
+  b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_dfs_probes.release();
+  b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
-  b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release();
+  b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release(); b->d_t_nruns.release();
+  b->d_run_tbase.release(); b->d_psort.release();
   if (b->side) (void)hipStreamDestroy(b->side);
   if (b->ev_seed_done) (void)hipEventDestroy(b->ev_seed_done);
   if (b->ev_pure_done) (void)hipEventDestroy(b->ev_pure_done);
   if (b->ev_cap_seed) (void)hipEventDestroy(b->ev_cap_seed);
-  if (b->ev_cap_pure) (void)hipEventDestroy(b->ev_cap_pure); b->d_probes.release(); b->d_fetches.release();
+  if (b->ev_cap_pure) (void)hipEventDestroy(b->ev_cap_pure);
+  if (b->ev_out) (void)hipEventDestroy(b->ev_out);
+  b->d_probes.release(); b->d_fetches.release();
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
   b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release(); b->d_stamps.release();
-  for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
-  if (b->pin) (void)hipHostFree(b->pin);
+  for (int i = 0; i < 7; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->d_out) (void)hipFree(b->d_out);
+  if (b->h_out) (void)hipHostFree(b->h_out);
   delete b;
   return KM_OK;
 }
@@ -796,7 +859,7 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
   b->h_item_off.assign(n + 1, 0);
   b->h_node_base.assign(n, 0);
   b->h_node_cap.assign(n, 0);
-  uint64_t pool = 0;
+  uint64_t pool = 0, total_ref = 0;
   uint32_t max_len = 0;
   for (uint32_t t = 0; t < n; ++t) {
     if (offsets[t + 1] < offsets[t]) return fail(KM_E_ARG, "offsets must be non-decreasing");
@@ -810,14 +873,21 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
     b->h_node_base[t] = pool;
     b->h_node_cap[t] = n_ref + FAST_EXTRA;
     pool += (uint64_t)n_ref + FAST_EXTRA;
+    total_ref += n_ref;
     max_len = std::max<uint32_t>(max_len, (uint32_t)L);
   }
   b->h_toff[n] = total;
-  b->node_pool_used = pool;
+  b->h_node_base0 = b->h_node_base;
+  b->h_node_cap0 = b->h_node_cap;
+  b->node_pool0 = b->node_pool_used = pool;
+  b->layout_moved = false;
   b->n_items = b->h_item_off[n];
   b->n_targets = n;
   b->total_bases = total;
+  b->total_ref = total_ref;
   b->max_len = max_len;
+  b->tail_guess = 4 * total_ref + total_ref / 2 + (64u << 10);
+  b->h_packed.clear();
   return KM_OK;
 }
 
@@ -846,6 +916,7 @@ static int push_layout(km_batch* b, hipStream_t st) {
   HIPCHK(hipStreamSynchronize(st));
   b->ran_walk = b->ran_graph = false;
   b->synced = true;
+  b->deliver_pending = b->result_ready = false;
   return KM_OK;
 }
 
@@ -922,6 +993,9 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.node_kmer = b->d_node_kmer.p;
   g.node_cnt = b->d_node_cnt.p;
   g.node_base = b->d_node_base.p;
+  g.packed = b->d_packed.p;
+  g.woff = b->d_woff.p;
+  g.words_cap = 0;
   g.n_nodes = b->d_n_nodes.p;
   g.n_ref = b->d_n_ref.p;
   g.status = b->d_status.p;
@@ -932,6 +1006,7 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.g_status = b->d_gstatus.p;
   g.t_npaths = b->d_npaths.p;
   g.t_pathbase = b->d_pathbase.p;
+  g.t_nruns = b->d_t_nruns.p;
   g.counters = b->d_counters.p;
   g.path_pool = b->path_pool;
   g.run_pool = b->run_pool;
@@ -951,26 +1026,65 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   if (b->graph_mode == 1) g.dbg = 1;       // duplicate check only
 }
 
-static void pure_geometry(km_batch* b) {
-  const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
-  b->ga.hcap_pure = round_up(4 * (max_nref + 2), 64);            // 32-bit fingerprints at load <= 1/4
-  b->pure_lds = b->ga.hcap_pure * 4;
-  if (b->pure_lds > FAST_LDS_LIMIT) { b->ga.hcap_pure = 64; b->pure_lds = 256; }   // all -> need_full
+// ---- fast-tier geometry.  The LDS-resident kernels are sized for the longest target of the
+// batch that still fits FAST_LDS_LIMIT; longer targets (and walks that outgrow the extra-node,
+// branch-frame or stack-frame allowance) are flagged T_NEEDS_BIG by the kernels themselves, one
+// by one, and finished by the large tier in km_batch_sync.  One long target does not demote the
+// rest of its batch.
+static uint32_t words_cap_for(uint32_t len) { return round_up((len + 31) / 32 + 1, 2); }
+
+static bool fast_fits(const km_batch* b, uint32_t nref, uint32_t bcap) {
+  const uint32_t len = nref + (uint32_t)b->db->k - 1;
+  const uint32_t wc = words_cap_for(len);
+  const uint32_t hs = round_up(2 * (nref + FAST_EXTRA), 64);
+  const uint32_t ncap = nref + FAST_EXTRA + 2, hcap = round_up(ncap + ncap / 2 + 1, 64);
+  return walk_lds_bytes(hs, wc, bcap) <= FAST_LDS_LIMIT &&
+         graph_ws_bytes<uint16_t>(ncap, hcap, wc) <= FAST_LDS_LIMIT && ncap < 0xFFFF &&
+         (uint64_t)hcap * 4 + (uint64_t)wc * 8 <= FAST_LDS_LIMIT;
+}
+
+static void fast_geometry(km_batch* b) {
+  const int k = b->db->k;
+  const uint32_t max_nref = b->max_len >= (uint32_t)k ? b->max_len - k + 1 : 1;
+  const uint32_t bcap = std::min<uint32_t>(b->p.max_break, FAST_BCAP_MAX - 1) + 1;
+  uint32_t nref = max_nref;
+  if (!fast_fits(b, nref, bcap)) {
+    uint32_t lo = 1, hi = max_nref;          // fits(lo) holds: a 1-k-mer target always fits
+    while (lo + 1 < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (fast_fits(b, mid, bcap)) lo = mid; else hi = mid;
+    }
+    nref = lo;
+  }
+  const uint32_t len = nref + (uint32_t)k - 1;
+  WalkArgs& wa = b->wa;
+  fill_walk_args(b, wa);
+  wa.hs_cap = round_up(2 * (nref + FAST_EXTRA), 64);
+  wa.words_cap = words_cap_for(len);
+  wa.fcap = round_up(std::min<uint32_t>(b->p.max_stack, FAST_FCAP_MAX - 2) + 2, 2);
+  wa.bcap = bcap;
+  wa.f_stride = walk_frame_bytes(wa.fcap);
+  b->walk_lds = (uint32_t)walk_lds_bytes(wa.hs_cap, wa.words_cap, wa.bcap);
+  GraphArgs& ga = b->ga;
+  fill_graph_args(b, ga);
+  ga.ncap = nref + FAST_EXTRA + 2;
+  ga.hcap = round_up(ga.ncap + ga.ncap / 2 + 1, 64);
+  ga.words_cap = wa.words_cap;
+  b->graph_lds = (uint32_t)graph_ws_bytes<uint16_t>(ga.ncap, ga.hcap, ga.words_cap);
+  ga.hcap_pure = round_up(4 * (nref + 2), 64);                   // 32-bit fingerprints at load <= 1/4
+  b->pure_lds = ga.hcap_pure * 4 + ga.words_cap * 8;
+  if (b->pure_lds > FAST_LDS_LIMIT) {                            // all -> need_full
+    ga.hcap_pure = 64;
+    b->pure_lds = 256 + ga.words_cap * 8;
+  }
 }
 
 // Graph stage on one stream: pure-chain pass, then the general kernel for the rest.
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
-  if (b->fast_ok) {
-    pure_geometry(b);
-    b->ga.use_need_full = 1;
-    hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, st, b->ga);
-    hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, b->ga);
-  } else {
-    // no LDS-resident tier for these parameters: mark everything for the large tier
-    HIPCHK(hipMemsetAsync(b->d_gstatus.p, 0, (uint64_t)b->n_targets * 4, st));
-    HIPCHK(hipMemsetAsync(b->d_npaths.p, 0, (uint64_t)b->n_targets * 4, st));
-  }
+  b->ga.use_need_full = 1;
+  hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, st, b->ga);
+  hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, b->ga);
   HIPCHK(hipGetLastError());
   return KM_OK;
 }
@@ -980,34 +1094,110 @@ static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
   else hipLaunchKernelGGL(k_seed<false>, dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
 }
 
+// Compaction kernels + ONE asynchronous copy of region A and the expected part of the tail into
+// the pinned twin; km_batch_result() waits for ev_out and fetches what the guess left behind.
+static int enqueue_deliver(km_batch* b, hipStream_t st) {
+  const uint32_t n = b->n_targets;
+  const OutLayout L = out_layout(n);
+  b->result_ready = false;
+  if (n == 0) {
+    memset(b->h_out, 0, L.a_bytes + 64);
+    reinterpret_cast<unsigned long long*>(b->h_out)[OT_TAIL_BYTES] = 16;
+    reinterpret_cast<unsigned long long*>(b->h_out)[OT_SERIAL] = ++b->serial;
+    b->copied_tail = 16;
+    b->deliver_pending = true;
+    HIPCHK(hipEventRecord(b->ev_out, st));
+    return KM_OK;
+  }
+  OutArgs oa;
+  memset(&oa, 0, sizeof oa);
+  oa.n_targets = n;
+  oa.ran_graph = (b->ran_graph && b->graph_mode == 0) ? 1u : 0u;
+  oa.serial = ++b->serial;
+  oa.status = b->d_status.p; oa.g_status = b->d_gstatus.p; oa.n_nodes = b->d_n_nodes.p; oa.n_ref = b->d_n_ref.p;
+  oa.t_npaths = b->d_npaths.p; oa.t_pathbase = b->d_pathbase.p; oa.t_nruns = b->d_t_nruns.p;
+  oa.probes = reinterpret_cast<unsigned long long*>(b->d_probes.p);
+  oa.dfs_probes = b->d_dfs_probes.p;
+  oa.fetches = reinterpret_cast<unsigned long long*>(b->d_fetches.p);
+  oa.pool_overflow = b->d_counters.p + POOL_GROUPS * POOL_CTR_STRIDE;
+  oa.n_flagged = b->d_nflagged.p;
+  oa.node_base = b->d_node_base.p; oa.node_kmer = b->d_node_kmer.p; oa.node_cnt = b->d_node_cnt.p;
+  oa.p_runbase = b->d_p_runbase.p; oa.p_nruns = b->d_p_nruns.p; oa.p_len = b->d_p_len.p;
+  oa.p_mincov = b->d_p_mincov.p; oa.r_start = b->d_r_start.p; oa.r_len = b->d_r_len.p;
+  oa.run_tbase = b->d_run_tbase.p; oa.psort = b->d_psort.p;
+  oa.totals = reinterpret_cast<unsigned long long*>(b->d_out + L.totals);
+  oa.o_status = reinterpret_cast<uint32_t*>(b->d_out + L.status);
+  oa.o_nref = reinterpret_cast<uint32_t*>(b->d_out + L.n_ref);
+  oa.o_probes = reinterpret_cast<uint64_t*>(b->d_out + L.probes);
+  oa.o_node_off = reinterpret_cast<uint64_t*>(b->d_out + L.node_off);
+  oa.o_extra_off = reinterpret_cast<uint64_t*>(b->d_out + L.extra_off);
+  oa.o_path_off = reinterpret_cast<uint32_t*>(b->d_out + L.path_off);
+  oa.tail = b->d_out + L.a_bytes;
+  oa.tail_cap = b->out_cap - L.a_bytes;
+  hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(OUT_SCAN_THREADS), 0, st, oa);
+  hipLaunchKernelGGL(k_out_pack, dim3(n), dim3(64), 0, st, oa);
+  HIPCHK(hipGetLastError());
+  if (b->timed) HIPCHK(hipEventRecord(b->ev[5], st));
+  const uint64_t guess = std::min<uint64_t>(oa.tail_cap, b->tail_guess);
+  HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, L.a_bytes + guess, hipMemcpyDeviceToHost, st));
+  if (b->timed) HIPCHK(hipEventRecord(b->ev[6], st));
+  b->timed_deliver = b->timed;
+  HIPCHK(hipEventRecord(b->ev_out, st));
+  b->copied_tail = guess;
+  b->deliver_pending = true;
+  return KM_OK;
+}
+
+// The large tier of an earlier run moved some targets to bigger node storage: back to the
+// layout of layout_targets (a step replays on the same targets start from the same state).
+static int restore_layout(km_batch* b, hipStream_t st) {
+  if (!b->layout_moved) return KM_OK;
+  drop_graph(b);
+  b->h_node_base = b->h_node_base0;
+  b->h_node_cap = b->h_node_cap0;
+  b->node_pool_used = b->node_pool0;
+  HIPCHK(hipMemcpyAsync(b->d_node_base.p, b->h_node_base.data(), (uint64_t)b->n_targets * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_node_cap.p, b->h_node_cap.data(), (uint64_t)b->n_targets * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  b->layout_moved = false;
+  return KM_OK;
+}
+
 extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   if (!b) return fail(KM_E_ARG, "null argument");
-  if (!b->n_targets) { b->ran_walk = true; b->ran_graph = (stages & KM_STAGE_GRAPH) != 0; return KM_OK; }
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = (hipStream_t)stream;
   b->last_stream = st;
   const bool want_graph = (stages & KM_RUN_HIPGRAPH) != 0;
+  const bool want_deliver = (stages & KM_RUN_DELIVER) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
+  b->deliver_pending = b->result_ready = false;
+  b->timed_deliver = false;
+  b->n_big = 0;
+  if (!b->n_targets) {
+    b->ran_walk = true;
+    b->ran_graph = (stages & KM_STAGE_GRAPH) != 0;
+    b->graph_mode = b->ran_graph ? 0 : 1;
+    b->synced = true;
+    return want_deliver ? enqueue_deliver(b, st) : KM_OK;
+  }
+  {
+    int rc = restore_layout(b, st);
+    if (rc != KM_OK) return rc;
+  }
   if (want_graph && b->gexec && b->graph_stages == stages && b->graph_stream == st) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
     b->ran_walk = true;
     b->ran_graph = true;
-    b->big_walk_done = false;
     b->synced = false;
     b->timed = false;
-    return KM_OK;
+    return want_deliver ? enqueue_deliver(b, st) : KM_OK;
   }
-  const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
 
-  // ---- fast-tier geometry
+  b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
+  fast_geometry(b);
   WalkArgs& wa = b->wa;
-  fill_walk_args(b, wa);
-  wa.hs_cap = round_up(2 * (max_nref + FAST_EXTRA), 64);
-  wa.words_cap = round_up((b->max_len + 31) / 32 + 1, 2);
-  wa.fcap = round_up(b->p.max_stack + 2, 2);
-  wa.bcap = b->p.max_break + 1;
-  const uint64_t wl = walk_lds_bytes(wa.hs_cap, wa.words_cap, wa.bcap);
-  wa.f_stride = walk_frame_bytes(wa.fcap);
+  GraphArgs& ga = b->ga;
   {
     int rc = b->d_frames.alloc((uint64_t)b->n_targets * wa.f_stride);
     if (rc != KM_OK) return rc;
@@ -1019,21 +1209,11 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     if (rc != KM_OK) return rc;
     wa.stamps = b->d_stamps.p;
   }
-  b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
-  GraphArgs& ga = b->ga;
-  fill_graph_args(b, ga);
-  ga.ncap = max_nref + FAST_EXTRA + 2;
-  ga.hcap = round_up(ga.ncap + ga.ncap / 2 + 1, 64);
-  const uint64_t gl = graph_ws_bytes<uint16_t>(ga.ncap, ga.hcap);
-  b->fast_ok = wl <= FAST_LDS_LIMIT && gl <= FAST_LDS_LIMIT && ga.ncap < 0xFFFF &&
-               b->p.max_break < 4096;
-  b->walk_lds = (uint32_t)wl;
-  b->graph_lds = (uint32_t)gl;
 
   bool graph_launched = false;
-  // a captured step needs the LDS-resident tier on both stages (no host round trips inside)
+  // a captured step has no host round trips inside
   b->timed = true;
-  const bool capturing = want_graph && st != nullptr && b->fast_ok && (stages & KM_STAGE_WALK);   // the NULL stream cannot be captured
+  const bool capturing = want_graph && st != nullptr && (stages & KM_STAGE_WALK);   // the NULL stream cannot be captured
   if (capturing) {
     b->timed = false;
     drop_graph(b);
@@ -1046,32 +1226,25 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     if (b->n_items)
       launch_seed(b->n_items, st, wa);
     if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
-    if (b->fast_ok) {
-      // unflagged targets are final after k_seed: their pure-chain check runs on the side
-      // stream while k_dfs (latency-bound, few waves) walks the flagged ones
-      HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
-      hipEvent_t e_fork = capturing ? b->ev_cap_seed : b->ev_seed_done;
-      hipEvent_t e_join = capturing ? b->ev_cap_pure : b->ev_pure_done;
-      HIPCHK(hipEventRecord(e_fork, st));
-      HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
-      pure_geometry(b);
-      ga.use_need_full = 1;
-      hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, b->side, ga);
-      HIPCHK(hipEventRecord(e_join, b->side));
-      hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
-      HIPCHK(hipGetLastError());
-      if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
-      HIPCHK(hipStreamWaitEvent(st, e_join, 0));
-      hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
-      HIPCHK(hipGetLastError());
-      graph_launched = true;
-    } else {
-      HIPCHK(hipGetLastError());
-      if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
-    }
+    // unflagged targets are final after k_seed: their pure-chain check runs on the side
+    // stream while k_dfs (latency-bound, few waves) walks the flagged ones
+    HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
+    hipEvent_t e_fork = capturing ? b->ev_cap_seed : b->ev_seed_done;
+    hipEvent_t e_join = capturing ? b->ev_cap_pure : b->ev_pure_done;
+    HIPCHK(hipEventRecord(e_fork, st));
+    HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
+    ga.use_need_full = 1;
+    hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, b->side, ga);
+    HIPCHK(hipEventRecord(e_join, b->side));
+    hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
+    HIPCHK(hipGetLastError());
+    if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
+    HIPCHK(hipStreamWaitEvent(st, e_join, 0));
+    hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+    HIPCHK(hipGetLastError());
+    graph_launched = true;
     b->ran_walk = true;
     b->ran_graph = false;
-    b->big_walk_done = false;
   } else if (!b->ran_walk) {
     return fail(KM_E_STATE, "graph stage requested before the walk stage");
   } else {
@@ -1096,20 +1269,16 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
   }
   b->synced = false;
-  return KM_OK;
+  return want_deliver ? enqueue_deliver(b, st) : KM_OK;
 }
 
 static int pull_status(km_batch* b, hipStream_t st) {
   const uint32_t n = b->n_targets;
   b->h_status.resize(n); b->h_gstatus.assign(n, 0); b->h_n_nodes.resize(n); b->h_n_ref.resize(n);
-  b->h_npaths.assign(n, 0); b->h_pathbase.assign(n, 0); b->h_probes.resize(n); b->h_fetches.resize(n);
+  b->h_npaths.assign(n, 0); b->h_pathbase.assign(n, 0);
   HIPCHK(hipMemcpyAsync(b->h_status.data(), b->d_status.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(b->h_n_nodes.data(), b->d_n_nodes.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(b->h_n_ref.data(), b->d_n_ref.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(b->h_probes.data(), b->d_probes.p, (uint64_t)n * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(b->h_fetches.data(), b->d_fetches.p, (uint64_t)n * 8, hipMemcpyDeviceToHost, st));
-  b->h_dfs_probes.resize(n);
-  HIPCHK(hipMemcpyAsync(b->h_dfs_probes.data(), b->d_dfs_probes.p, (uint64_t)n * 8, hipMemcpyDeviceToHost, st));
   if (b->ran_graph) {
     HIPCHK(hipMemcpyAsync(b->h_gstatus.data(), b->d_gstatus.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_npaths.data(), b->d_npaths.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -1117,11 +1286,6 @@ static int pull_status(km_batch* b, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(&b->h_overflow, b->d_counters.p + POOL_GROUPS * POOL_CTR_STRIDE, 8, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(hipStreamSynchronize(st));
-  b->h_seed_probes = 0;
-  for (uint32_t t = 0; t < n; ++t) {
-    b->h_seed_probes += b->h_probes[t];
-    b->h_probes[t] += b->h_dfs_probes[t];
-  }
   return KM_OK;
 }
 
@@ -1129,6 +1293,8 @@ static int pull_status(km_batch* b, hipStream_t st) {
 static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream_t st) {
   const uint32_t nb = (uint32_t)ids.size();
   const int k = b->db->k;
+  drop_graph(b);                      // a captured step holds the addresses that change below
+  b->layout_moved = true;
   // per-target node storage big enough for the reference's own bound
   uint64_t extra = 0;
   std::vector<uint64_t> old_base;
@@ -1155,13 +1321,11 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
     b->d_node_kmer = nk; b->d_node_cnt = nc;
   }
   b->node_pool_used = need;
-  // the seed kernel's results (target k-mers and their counts) move to the new storage
+  // the seed kernel's results (the counts of the target's own k-mers) move to the new storage
   for (size_t q = 0; q < ids.size(); ++q) {
     const uint32_t t = ids[q];
     const uint64_t nref = b->h_n_ref[t];
     if (!nref) continue;
-    HIPCHK(hipMemcpyAsync(b->d_node_kmer.p + b->h_node_base[t], b->d_node_kmer.p + old_base[q], nref * 8,
-                          hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_node_cnt.p + b->h_node_base[t], b->d_node_cnt.p + old_base[q], nref * 4,
                           hipMemcpyDeviceToDevice, st));
   }
@@ -1178,7 +1342,7 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   const uint64_t hs = 2 * (max_nodes + b->p.max_stack + 64);
   if (hs > 0x7FFFFF00ull) return fail(KM_E_ARG, "node limit too large");
   a.hs_cap = round_up((uint32_t)hs, 64);
-  a.words_cap = round_up((b->max_len + 31) / 32 + 1, 2);
+  a.words_cap = words_cap_for(b->max_len);
   a.fcap = round_up(b->p.max_stack + 2, 2);
   a.bcap = b->p.max_break + 1;
   a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap);
@@ -1208,7 +1372,8 @@ static int run_big_graph(km_batch* b, const std::vector<uint32_t>& ids, hipStrea
   fill_graph_args(b, g);
   g.ncap = max_nodes + 2;
   g.hcap = round_up(g.ncap + g.ncap / 2 + 1, 64);
-  g.g_stride = graph_ws_bytes<uint32_t>(g.ncap, g.hcap);
+  g.words_cap = words_cap_for(b->max_len);
+  g.g_stride = graph_ws_bytes<uint32_t>(g.ncap, g.hcap, g.words_cap);
   const uint64_t budget = 8ull << 30;
   uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb, budget / g.g_stride));
   rc = b->d_big_ws.alloc((uint64_t)per * g.g_stride); if (rc != KM_OK) return rc;
@@ -1224,26 +1389,43 @@ static int run_big_graph(km_batch* b, const std::vector<uint32_t>& ids, hipStrea
 }
 
 static int grow_path_pools(km_batch* b) {
+  drop_graph(b);                      // a captured step holds the old pool addresses and sizes
   b->path_pool = (b->path_pool * 4 / POOL_GROUPS + 1) * POOL_GROUPS;
   b->run_pool = (b->run_pool * 4 / POOL_GROUPS + 1) * POOL_GROUPS;
   int rc = KM_OK;
   auto A = [&](int r) { if (rc == KM_OK) rc = r; };
   A(b->d_p_target.alloc(b->path_pool)); A(b->d_p_runbase.alloc(b->path_pool));
   A(b->d_p_nruns.alloc(b->path_pool)); A(b->d_p_len.alloc(b->path_pool));
-  A(b->d_p_mincov.alloc(b->path_pool)); A(b->d_r_start.alloc(b->run_pool));
-  A(b->d_r_len.alloc(b->run_pool));
+  A(b->d_p_mincov.alloc(b->path_pool)); A(b->d_psort.alloc(b->path_pool));
+  A(b->d_r_start.alloc(b->run_pool)); A(b->d_r_len.alloc(b->run_pool));
   return rc;
 }
 
 static int relaunch_fast_graph(km_batch* b, hipStream_t st) {
+  // same geometry as the run, new pool sizes / addresses
+  const GraphArgs old = b->ga;
   fill_graph_args(b, b->ga);
-  const uint32_t max_nref = b->max_len >= (uint32_t)b->db->k ? b->max_len - b->db->k + 1 : 1;
-  b->ga.ncap = max_nref + FAST_EXTRA + 2;
-  b->ga.hcap = round_up(b->ga.ncap + b->ga.ncap / 2 + 1, 64);
+  b->ga.ncap = old.ncap; b->ga.hcap = old.hcap; b->ga.words_cap = old.words_cap; b->ga.hcap_pure = old.hcap_pure;
   int rc = launch_graph_fast(b, st);
   if (rc != KM_OK) return rc;
   HIPCHK(hipStreamSynchronize(st));
   return KM_OK;
+}
+
+static void read_timings(km_batch* b) {
+  for (float& v : b->ms) v = 0.0f;
+  if (!b->timed) return;
+  (void)hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]);
+  (void)hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]);
+  (void)hipEventElapsedTime(&b->ms[2], b->ev[0], b->ev[2]);
+  (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
+  (void)hipEventElapsedTime(&b->ms[4], b->ev[0], b->ev[3]);
+  (void)hipEventElapsedTime(&b->ms[5], b->ev[4], b->ev[1]);
+  if (b->timed_deliver) {
+    (void)hipEventElapsedTime(&b->ms[6], b->ev[2], b->ev[5]);
+    (void)hipEventElapsedTime(&b->ms[7], b->ev[5], b->ev[6]);
+  }
+  (void)hipGetLastError();
 }
 
 // Wait for the launched kernels, then finish the rare work that needs the host:
@@ -1255,41 +1437,24 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = b->last_stream;
   HIPCHK(hipStreamSynchronize(st));
-  if (b->timed) {
-    (void)hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]);
-    (void)hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]);
-    (void)hipEventElapsedTime(&b->ms[2], b->ev[0], b->ev[2]);
-    (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
-    (void)hipGetLastError();
-  } else {
-    b->ms[0] = b->ms[1] = b->ms[2] = b->ms[3] = 0.0f;
-  }
-  HIPCHK(hipMemcpy(&b->h_nflagged, b->d_nflagged.p, 4, hipMemcpyDeviceToHost));
+  read_timings(b);
+  if (!b->n_targets) { b->synced = true; return KM_OK; }
   int rc = pull_status(b, st);
   if (rc != KM_OK) return rc;
   const uint32_t n = b->n_targets;
 
   std::vector<uint32_t> big;
-  if (b->fast_ok) {
-    for (uint32_t t = 0; t < n; ++t) if (b->h_status[t] == T_NEEDS_BIG) big.push_back(t);
-  } else if (!b->big_walk_done) {
-    // no LDS-resident tier for these parameters: every flagged target takes the large tier
-    uint32_t nf = 0;
-    HIPCHK(hipMemcpy(&nf, b->d_nflagged.p, 4, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> fl(nf);
-    if (nf) HIPCHK(hipMemcpy(fl.data(), b->d_flagged.p, (uint64_t)nf * 4, hipMemcpyDeviceToHost));
-    for (uint32_t t : fl) if (b->h_status[t] == T_OK) big.push_back(t);
-    std::sort(big.begin(), big.end());
-  }
-  b->big_walk_done = true;
+  for (uint32_t t = 0; t < n; ++t) if (b->h_status[t] == T_NEEDS_BIG) big.push_back(t);
   b->n_big = (uint32_t)big.size();
   std::vector<char> force_big(n, 0);
+  bool changed = false;
   if (!big.empty()) {
     rc = run_big_walk(b, big, st);
     if (rc != KM_OK) return rc;
     for (uint32_t t : big) force_big[t] = 1;     // the fast graph pass skipped them
     rc = pull_status(b, st);
     if (rc != KM_OK) return rc;
+    changed = true;
   }
   if (b->ran_graph) {
     for (int pass = 0;; ++pass) {
@@ -1302,6 +1467,7 @@ extern "C" int km_batch_sync(km_batch_t* b) {
         rc = pull_status(b, st);
         if (rc != KM_OK) return rc;
         std::fill(force_big.begin(), force_big.end(), 0);   // the relaunch saw their final walk status
+        changed = true;
       }
       std::vector<uint32_t> todo;
       for (uint32_t t = 0; t < n; ++t)
@@ -1311,11 +1477,107 @@ extern "C" int km_batch_sync(km_batch_t* b) {
         if (rc != KM_OK) return rc;
         rc = pull_status(b, st);
         if (rc != KM_OK) return rc;
+        changed = true;
       }
       if (!b->h_overflow) break;
     }
   }
+  if (changed) b->deliver_pending = b->result_ready = false;   // any earlier delivery is stale
   b->synced = true;
+  return KM_OK;
+}
+
+// Results of the last run in the pinned delivery buffer (delivering now if the run did not).
+static int finish_result(km_batch* b) {
+  if (!b->ran_walk) return fail(KM_E_STATE, "nothing has run yet");
+  if (b->result_ready) return KM_OK;
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t st = b->last_stream;
+  if (!b->deliver_pending) {
+    int rc = km_batch_sync(b);
+    if (rc != KM_OK) return rc;
+    rc = enqueue_deliver(b, st);
+    if (rc != KM_OK) return rc;
+  }
+  const OutLayout L = out_layout(b->n_targets);
+  const unsigned long long* T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
+  for (int attempt = 0;; ++attempt) {
+    HIPCHK(hipEventSynchronize(b->ev_out));
+    if (T[OT_SERIAL] != b->serial) return fail(KM_E_HIP, "delivery buffer out of step");
+    const unsigned long long nh = T[OT_NEEDS_HOST];
+    if (!nh) break;
+    if (attempt >= 4) return fail(KM_E_NOMEM, "result delivery keeps failing");
+    if (nh & 1ull) {
+      b->synced = false;
+      int rc = km_batch_sync(b);
+      if (rc != KM_OK) return rc;
+    }
+    if (nh == 2ull) {
+      // everything is final, only the tail is larger than the buffer
+      HIPCHK(hipStreamSynchronize(st));
+      int rc = ensure_out(b, T[OT_TAIL_BYTES] + 4096);
+      if (rc != KM_OK) return rc;
+    } else {
+      HIPCHK(hipStreamSynchronize(st));
+      int rc = ensure_out(b, default_tail_bytes(b, b->node_pool_used, b->node_pool_used));
+      if (rc != KM_OK) return rc;
+    }
+    T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
+    int rc = enqueue_deliver(b, st);
+    if (rc != KM_OK) return rc;
+  }
+  const uint64_t tail = T[OT_TAIL_BYTES];
+  if (tail > b->copied_tail)
+    HIPCHK(hipMemcpy(b->h_out + L.a_bytes + b->copied_tail, b->d_out + L.a_bytes + b->copied_tail,
+                     tail - b->copied_tail, hipMemcpyDeviceToHost));
+  b->tail_guess = tail + tail / 16 + 4096;
+  b->deliver_pending = false;
+  b->result_ready = true;
+  return KM_OK;
+}
+
+static void view_of_result(const km_batch* b, km_batch_out_t* v) {
+  const OutLayout L = out_layout(b->n_targets);
+  unsigned char* h = b->h_out;
+  const unsigned long long* T = reinterpret_cast<const unsigned long long*>(h + L.totals);
+  unsigned char* tail = h + L.a_bytes;
+  memset(v, 0, sizeof *v);
+  v->status = reinterpret_cast<uint32_t*>(h + L.status);
+  v->n_ref = reinterpret_cast<uint32_t*>(h + L.n_ref);
+  v->probes = reinterpret_cast<uint64_t*>(h + L.probes);
+  v->node_off = reinterpret_cast<uint64_t*>(h + L.node_off);
+  v->extra_off = reinterpret_cast<uint64_t*>(h + L.extra_off);
+  v->path_off = reinterpret_cast<uint32_t*>(h + L.path_off);
+  v->node_count = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_COUNT]);
+  v->extra_kmer = reinterpret_cast<uint64_t*>(tail + T[OT_OFF_EXTRA]);
+  v->path_len = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_PLEN]);
+  v->path_min_cov = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_PMIN]);
+  v->run_off = reinterpret_cast<uint64_t*>(tail + T[OT_OFF_RUNOFF]);
+  v->run_start = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_RSTART]);
+  v->run_len = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_RLEN]);
+}
+
+static void sizes_of_result(const km_batch* b, km_batch_sizes_t* s) {
+  const unsigned long long* T = reinterpret_cast<const unsigned long long*>(b->h_out + out_layout(b->n_targets).totals);
+  memset(s, 0, sizeof *s);
+  s->n_targets = b->n_targets;
+  s->n_paths = (uint32_t)T[OT_N_PATHS];
+  s->n_nodes = T[OT_N_NODES];
+  s->n_runs = T[OT_N_RUNS];
+  s->n_extra = T[OT_N_EXTRA];
+  s->logical_probes = T[OT_PROBES];
+  s->table_fetches = T[OT_FETCHES];
+  s->n_big_tier = b->n_big;
+  s->n_flagged = (uint32_t)T[OT_N_FLAGGED];
+  s->seed_probes = T[OT_SEED_PROBES];
+}
+
+extern "C" int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes) {
+  if (!b) return fail(KM_E_ARG, "null argument");
+  int rc = finish_result(b);
+  if (rc != KM_OK) return rc;
+  if (view) view_of_result(b, view);
+  if (sizes) sizes_of_result(b, sizes);
   return KM_OK;
 }
 
@@ -1331,157 +1593,70 @@ extern "C" int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_
   return KM_OK;
 }
 
-extern "C" int km_batch_timings(km_batch_t* b, float* ms4) {
-  float* ms3 = ms4;
+extern "C" int km_batch_timings(km_batch_t* b, float* ms8) {
+  float* ms3 = ms8;
   if (!b || !ms3) return fail(KM_E_ARG, "null argument");
-  int rc = km_batch_sync(b);
-  if (rc != KM_OK) return rc;
-  ms3[0] = b->ms[0]; ms3[1] = b->ms[1]; ms3[2] = b->ms[2]; ms3[3] = b->ms[3];
+  if (!b->synced) {
+    // timing events only: no status pull, no large tier (finish_result does that when asked)
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->last_stream));
+    read_timings(b);
+  }
+  for (int i = 0; i < 8; ++i) ms3[i] = b->ms[i];
   return KM_OK;
 }
 
 extern "C" int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* s) {
   if (!b || !s) return fail(KM_E_ARG, "null argument");
-  if (!b->ran_walk) return fail(KM_E_STATE, "nothing has run yet");
-  int rc = km_batch_sync(b);
-  if (rc != KM_OK) return rc;
-  memset(s, 0, sizeof *s);
-  s->n_targets = b->n_targets;
-  s->n_big_tier = b->n_big;
-  s->n_flagged = b->h_nflagged;
-  s->seed_probes = b->h_seed_probes;
-  uint64_t paths = 0;
-  for (uint32_t t = 0; t < b->n_targets; ++t) {
-    if (b->h_status[t] == T_OK || b->h_status[t] == T_NODE_LIMIT) s->n_nodes += b->h_n_nodes[t];
-    s->logical_probes += b->h_probes[t];
-    s->table_fetches += b->h_fetches[t];
-    paths += b->h_npaths[t];
-  }
-  s->n_paths = (uint32_t)paths;
-  // runs: sum over the path records actually referenced
-  if (b->ran_graph && paths) {
-    std::vector<uint32_t> nruns((size_t)b->path_pool);
-    HIPCHK(hipMemcpy(nruns.data(), b->d_p_nruns.p, nruns.size() * 4, hipMemcpyDeviceToHost));
-    for (uint32_t t = 0; t < b->n_targets; ++t)
-      for (uint32_t i = 0; i < b->h_npaths[t]; ++i) s->n_runs += nruns[b->h_pathbase[t] + i];
-  }
-  return KM_OK;
+  return km_batch_result(b, nullptr, s);
 }
 
-namespace {
-struct PathRec {
-  const uint32_t* rs;
-  const uint32_t* rl;
-  uint32_t nruns, len, mincov;
-};
-// lexicographic order of the expanded index sequences
-bool path_less(const PathRec& A, const PathRec& B) {
-  uint32_t ia = 0, ib = 0, oa = 0, ob = 0;
-  while (ia < A.nruns && ib < B.nruns) {
-    const uint32_t va = A.rs[ia] + oa, vb = B.rs[ib] + ob;
-    if (va != vb) return va < vb;
-    const uint32_t step = std::min(A.rl[ia] - oa, B.rl[ib] - ob);
-    oa += step; ob += step;
-    if (oa == A.rl[ia]) { ++ia; oa = 0; }
-    if (ob == B.rl[ib]) { ++ib; ob = 0; }
-  }
-  return ia == A.nruns && ib < B.nruns;
-}
-}  // namespace
-
+// Copying variant of km_batch_result: fills caller-allocated arrays (sizes from km_batch_sizes).
+// node_kmer, when asked for, is rebuilt here: the target's own k-mers from the packed targets,
+// the walk-discovered ones from extra_kmer.
 extern "C" int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out) {
   if (!b || !out) return fail(KM_E_ARG, "null argument");
-  if (!b->ran_walk) return fail(KM_E_STATE, "nothing has run yet");
-  int rc = km_batch_sync(b);
+  int rc = finish_result(b);
   if (rc != KM_OK) return rc;
-  HIPCHK(hipSetDevice(b->device));
+  km_batch_out_t v;
+  km_batch_sizes_t s;
+  view_of_result(b, &v);
+  sizes_of_result(b, &s);
   const uint32_t n = b->n_targets;
-  for (uint32_t t = 0; t < n; ++t) {
-    if (out->status) out->status[t] = b->h_status[t] == T_OK && b->h_gstatus[t] != T_OK ? KM_T_INTERNAL
-                                                                                     : b->h_status[t];
-    if (out->aux) out->aux[t] = 0;
-    if (out->n_ref) out->n_ref[t] = b->h_n_ref[t];
-    if (out->probes) out->probes[t] = b->h_probes[t];
-  }
-  // ---- nodes (CSR in target order)
-  if (out->node_off || out->node_kmer || out->node_count) {
-    std::vector<uint64_t> noff(n + 1, 0);
+  if (out->status) memcpy(out->status, v.status, 4ull * n);
+  if (out->aux) memset(out->aux, 0, 4ull * n);
+  if (out->n_ref) memcpy(out->n_ref, v.n_ref, 4ull * n);
+  if (out->probes) memcpy(out->probes, v.probes, 8ull * n);
+  if (out->node_off) memcpy(out->node_off, v.node_off, 8ull * (n + 1));
+  if (out->extra_off) memcpy(out->extra_off, v.extra_off, 8ull * (n + 1));
+  if (out->node_count) memcpy(out->node_count, v.node_count, 4 * s.n_nodes);
+  if (out->extra_kmer) memcpy(out->extra_kmer, v.extra_kmer, 8 * s.n_extra);
+  if (out->path_off) memcpy(out->path_off, v.path_off, 4ull * (n + 1));
+  if (out->run_off) memcpy(out->run_off, v.run_off, 8ull * (s.n_paths + 1));
+  if (out->run_start) memcpy(out->run_start, v.run_start, 4 * s.n_runs);
+  if (out->run_len) memcpy(out->run_len, v.run_len, 4 * s.n_runs);
+  if (out->path_len) memcpy(out->path_len, v.path_len, 4ull * s.n_paths);
+  if (out->path_min_cov) memcpy(out->path_min_cov, v.path_min_cov, 4ull * s.n_paths);
+  if (out->node_kmer && n) {
+    HIPCHK(hipSetDevice(b->device));
+    if (b->h_packed.empty()) {
+      b->h_packed.resize(b->h_woff[n]);
+      HIPCHK(hipMemcpy(b->h_packed.data(), b->d_packed.p, b->h_woff[n] * 8, hipMemcpyDeviceToHost));
+    }
+    const int k = b->db->k;
     for (uint32_t t = 0; t < n; ++t) {
-      const bool has = b->h_status[t] == T_OK || b->h_status[t] == T_NODE_LIMIT;
-      noff[t + 1] = noff[t] + (has ? b->h_n_nodes[t] : 0);
-    }
-    if (out->node_off) memcpy(out->node_off, noff.data(), (n + 1) * 8);
-    if (out->node_kmer || out->node_count) {
-      // pull the used part of the pools through a pinned staging buffer, compact on the host
-      const uint64_t used = b->node_pool_used;
-      const uint64_t need = used * 12 + 64;
-      if (need > b->pin_cap) {
-        if (b->pin) (void)hipHostFree(b->pin);
-        b->pin = nullptr;
-        b->pin_cap = 0;
-        HIPCHK(hipHostMalloc((void**)&b->pin, need + need / 4, hipHostMallocDefault));
-        b->pin_cap = need + need / 4;
+      const uint64_t a0 = v.node_off[t], cnt = v.node_off[t + 1] - a0;
+      if (!cnt) continue;
+      const uint64_t ne = v.extra_off[t + 1] - v.extra_off[t], nr = cnt - ne;
+      const uint64_t* words = b->h_packed.data() + b->h_woff[t];
+      uint64_t* dst = out->node_kmer + a0;
+      for (uint64_t i = 0; i < nr; ++i) {
+        const uint64_t w = i >> 5, sh = (i & 31) * 2;
+        const uint64_t x = sh ? ((words[w] << sh) | (words[w + 1] >> (64 - sh))) : words[w];
+        dst[i] = x >> (64 - 2 * k);
       }
-      const uint64_t* hk = reinterpret_cast<const uint64_t*>(b->pin);
-      const uint32_t* hc = reinterpret_cast<const uint32_t*>(b->pin + used * 8);
-      if (out->node_kmer && used)
-        HIPCHK(hipMemcpy(b->pin, b->d_node_kmer.p, used * 8, hipMemcpyDeviceToHost));
-      if (out->node_count && used)
-        HIPCHK(hipMemcpy(b->pin + used * 8, b->d_node_cnt.p, used * 4, hipMemcpyDeviceToHost));
-      for (uint32_t t = 0; t < n; ++t) {
-        const uint64_t cnt = noff[t + 1] - noff[t];
-        if (!cnt) continue;
-        if (out->node_kmer) memcpy(out->node_kmer + noff[t], hk + b->h_node_base[t], cnt * 8);
-        if (out->node_count) memcpy(out->node_count + noff[t], hc + b->h_node_base[t], cnt * 4);
-      }
+      memcpy(dst + nr, v.extra_kmer + v.extra_off[t], 8 * ne);
     }
-  }
-  // ---- paths
-  if (b->ran_graph && (out->path_off || out->run_off || out->run_start || out->run_len ||
-                       out->path_len || out->path_min_cov)) {
-    const uint64_t np = b->path_pool, nr = b->run_pool;
-    std::vector<uint32_t> p_nruns(np), p_len(np), p_mincov(np), r_start(nr), r_len(nr);
-    std::vector<uint64_t> p_runbase(np);
-    if (np) {
-      HIPCHK(hipMemcpy(p_nruns.data(), b->d_p_nruns.p, np * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(p_len.data(), b->d_p_len.p, np * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(p_mincov.data(), b->d_p_mincov.p, np * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(p_runbase.data(), b->d_p_runbase.p, np * 8, hipMemcpyDeviceToHost));
-    }
-    if (nr) {
-      HIPCHK(hipMemcpy(r_start.data(), b->d_r_start.p, nr * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(r_len.data(), b->d_r_len.p, nr * 4, hipMemcpyDeviceToHost));
-    }
-    uint32_t pcur = 0;
-    uint64_t rcur = 0;
-    std::vector<PathRec> recs;
-    for (uint32_t t = 0; t < n; ++t) {
-      if (out->path_off) out->path_off[t] = pcur;
-      recs.clear();
-      for (uint32_t i = 0; i < b->h_npaths[t]; ++i) {
-        const uint64_t pi = (uint64_t)b->h_pathbase[t] + i;
-        PathRec r{r_start.data() + p_runbase[pi], r_len.data() + p_runbase[pi], p_nruns[pi], p_len[pi],
-                  p_mincov[pi]};
-        recs.push_back(r);
-      }
-      std::sort(recs.begin(), recs.end(), path_less);
-      for (const PathRec& r : recs) {
-        if (out->run_off) out->run_off[pcur] = rcur;
-        if (out->path_len) out->path_len[pcur] = r.len;
-        if (out->path_min_cov) out->path_min_cov[pcur] = r.mincov;
-        for (uint32_t j = 0; j < r.nruns; ++j) {
-          if (out->run_start) out->run_start[rcur + j] = r.rs[j];
-          if (out->run_len) out->run_len[rcur + j] = r.rl[j];
-        }
-        rcur += r.nruns;
-        ++pcur;
-      }
-    }
-    if (out->path_off) out->path_off[n] = pcur;
-    if (out->run_off) out->run_off[pcur] = rcur;
-  } else if (out->path_off) {
-    for (uint32_t t = 0; t <= n; ++t) out->path_off[t] = 0;
-    if (out->run_off) out->run_off[0] = 0;
   }
   return KM_OK;
 }

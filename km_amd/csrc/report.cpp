@@ -41,7 +41,8 @@ struct Target {
   size_t seq_len;
   int k;
   int64_t n_ref;
-  const uint64_t* kmers;
+  const uint64_t* kmers;    // all nodes, or NULL: then node i < n_ref is the k-mer at base i of seq
+  const uint64_t* extra;    // ... and node n_ref + j is extra[j]
   const uint32_t* counts;
   int64_t n_nodes;
   std::vector<Path> paths;
@@ -52,7 +53,19 @@ struct Split { int64_t start, end_ref, end_var, end_ovl; };
 
 const char LAST[4] = {'A', 'C', 'G', 'T'};
 
-inline char tail_of(const Target& t, int64_t node) { return LAST[t.kmers[node] & 3]; }
+inline uint64_t base_code(char c) { return ((uint64_t)(c >> 1) ^ (uint64_t)(c >> 2)) & 3u; }   // either case
+inline uint64_t kmer_of(const Target& t, int64_t node) {
+  if (t.kmers) return t.kmers[node];
+  if (node >= t.n_ref) return t.extra[node - t.n_ref];
+  uint64_t x = 0;
+  for (int j = 0; j < t.k; ++j) x = (x << 2) | base_code(t.seq[node + j]);
+  return x;
+}
+inline char tail_of(const Target& t, int64_t node) {
+  if (t.kmers) return LAST[t.kmers[node] & 3];
+  if (node >= t.n_ref) return LAST[t.extra[node - t.n_ref] & 3];
+  return LAST[base_code(t.seq[node + t.k - 1])];
+}
 
 // Python index semantics of numpy fancy indexing on a 1-D array of length n
 inline bool wrap_index(int64_t i, int64_t n, int64_t* out) {
@@ -117,7 +130,7 @@ std::string unpack(uint64_t kmer, int k) {
 
 std::string spell(const Target& t, const Path& p, bool whole_first) {
   if (p.empty()) return std::string();
-  std::string s = whole_first ? unpack(t.kmers[p[0]], t.k) : std::string(1, tail_of(t, p[0]));
+  std::string s = whole_first ? unpack(kmer_of(t, p[0]), t.k) : std::string(1, tail_of(t, p[0]));
   s.reserve(s.size() + p.size());
   for (size_t i = 1; i < p.size(); ++i) s.push_back(tail_of(t, p[i]));
   return s;
@@ -503,7 +516,8 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
                               int32_t** err_out) {
   if (!in || !text_out || !row_off_out || !err_out || !in->res) return KM_E_ARG;
   const km_batch_out_t& r = *in->res;
-  if (!r.status || !r.n_ref || !r.node_off || !r.node_kmer || !r.node_count || !r.path_off || !r.run_off ||
+  if (!r.status || !r.n_ref || !r.node_off || (!r.node_kmer && (!r.extra_off || !r.extra_kmer)) ||
+      !r.node_count || !r.path_off || !r.run_off ||
       !r.run_start || !r.run_len || !r.path_min_cov || (in->n_targets && (!in->bases || !in->base_off || !in->names)))
     return KM_E_ARG;
   if (in->k < 2 || in->k > 32) return KM_E_K;
@@ -530,7 +544,8 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
           t.seq_len = (size_t)(in->base_off[ti + 1] - in->base_off[ti]);
           t.k = in->k;
           t.n_ref = r.n_ref[ti];
-          t.kmers = r.node_kmer + r.node_off[ti];
+          t.kmers = r.node_kmer ? r.node_kmer + r.node_off[ti] : nullptr;
+          t.extra = r.node_kmer ? nullptr : r.extra_kmer + r.extra_off[ti];
           t.counts = r.node_count + r.node_off[ti];
           t.n_nodes = (int64_t)(r.node_off[ti + 1] - r.node_off[ti]);
           const uint32_t p0 = r.path_off[ti], p1 = r.path_off[ti + 1];

@@ -371,7 +371,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
     c4 = finish_children(tab, X, g.flip, c4);
     KM_SEED_STAMP(6);
     if constexpr (STAMPS) probes_first = fetch_l;
-    a.node_kmer[nb + i] = X;
+    // (the k-mer itself is not stored: every consumer reads the target's own k-mers from its
+    // packed words; node_kmer[] holds walk-discovered nodes only)
     uint32_t nextb = 4;
     if (i + 1 < n_ref) {
       // last base of ref[i+1] = base k of this lane's 32-base window (k <= 31), else reloaded
@@ -626,8 +627,9 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               slot = set_find(keys, cap, child, &found);
               if (slot < 0 || found) { st = T_INTERNAL; break; }
             }
+            if (depth >= a.fcap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }   // fast tier: bounded frames
             if (mask != 0) {
-              if (bsp >= a.bcap) { st = T_INTERNAL; break; }
+              if (bsp >= a.bcap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
               if (lane == 0) {
                 BranchFrame f;
                 f.c4 = c4; f.depth = depth; f.mask = mask; f.brk = brk; f.pad = 0;

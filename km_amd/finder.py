@@ -78,8 +78,10 @@ class BatchFinder:
         packed = _lib.pack_sequences(seqs)               # encoded once, for the GPU and for the report
         b = self._ensure(len(seqs), int(packed[1][-1]))
         b.set_targets_packed(*packed)
-        b.run()
-        raw = b.fetch()
+        # kernels + device-side compaction + one asynchronous D2H into the batch's pinned buffer;
+        # `raw` are views into that buffer (no host reorganisation, no copy)
+        b.run(_lib.KM_STAGE_WALK | _lib.KM_STAGE_GRAPH | _lib.KM_RUN_DELIVER)
+        raw = b.result()
         self._raise_input_errors(raw, names, seqs)
         out = _lib.report_rows(raw, names, seqs, self.jf.k, self.jf.filename if db_name is None else db_name,
                                packed=packed)

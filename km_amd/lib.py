@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkmgpu.so")
 
 KM_OK = 0
-KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH = 1, 2, 4
+KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER = 1, 2, 4, 8
 T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 
 # every symbol include/kmgpu.h declares (tests check the library exports them all)
@@ -23,7 +23,7 @@ SYMBOLS = [
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
-    "km_batch_sizes", "km_batch_fetch", "km_batch_timings", "km_batch_debug_stamps",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_debug_stamps",
     "km_report_rows", "km_report_free", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
@@ -50,7 +50,7 @@ class BatchSizes(C.Structure):
     _fields_ = [("n_targets", C.c_uint32), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint64),
                 ("n_runs", C.c_uint64), ("logical_probes", C.c_uint64),
                 ("table_fetches", C.c_uint64), ("n_big_tier", C.c_uint32), ("n_flagged", C.c_uint32),
-                ("seed_probes", C.c_uint64)]
+                ("seed_probes", C.c_uint64), ("n_extra", C.c_uint64)]
 
 
 _P32 = C.POINTER(C.c_uint32)
@@ -61,7 +61,7 @@ class BatchOut(C.Structure):
     _fields_ = [("status", _P32), ("aux", _P32), ("n_ref", _P32), ("probes", _P64),
                 ("node_off", _P64), ("node_kmer", _P64), ("node_count", _P32),
                 ("path_off", _P32), ("run_off", _P64), ("run_start", _P32), ("run_len", _P32),
-                ("path_len", _P32), ("path_min_cov", _P32)]
+                ("path_len", _P32), ("path_min_cov", _P32), ("extra_off", _P64), ("extra_kmer", _P64)]
 
 
 class ReportIn(C.Structure):
@@ -107,6 +107,7 @@ def load():
         "km_batch_sync": [vp],
         "km_batch_sizes": [vp, C.POINTER(BatchSizes)],
         "km_batch_fetch": [vp, C.POINTER(BatchOut)],
+        "km_batch_result": [vp, C.POINTER(BatchOut), C.POINTER(BatchSizes)],
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
         "km_batch_debug_stamps": [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)],
         "km_report_rows": [C.POINTER(ReportIn), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
@@ -314,9 +315,9 @@ class Batch:
         check(self._lib.km_batch_sync(self._b))
 
     def timings(self):
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 8)()
         check(self._lib.km_batch_timings(self._b, ms))
-        return float(ms[0]), float(ms[1]), float(ms[2]), float(ms[3])
+        return tuple(float(x) for x in ms)
 
     def debug_stamps(self):
         """k_seed time stamps (KM_SEED_STAMPS diagnostics): uint64 array [n_waves, 16]."""
@@ -332,8 +333,45 @@ class Batch:
         check(self._lib.km_batch_sizes(self._b, C.byref(s)))
         return s
 
+    def wait_result(self):
+        """Wait for the delivery of the last run (km_batch_result without building views);
+        returns the batch sizes."""
+        s = BatchSizes()
+        check(self._lib.km_batch_result(self._b, None, C.byref(s)))
+        return s
+
+    def result(self):
+        """Results of the last run as numpy views INTO the batch's pinned delivery buffer (no
+        copy; valid until the next run / set_targets on this batch).  `node_kmer` is absent:
+        node i < n_ref of a target is the k-mer at base i of the target, the walk-discovered
+        nodes are in `extra_kmer` (CSR `extra_off`)."""
+        out, s = BatchOut(), BatchSizes()
+        check(self._lib.km_batch_result(self._b, C.byref(out), C.byref(s)))
+        n = s.n_targets
+
+        def view(p, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(p, shape=(int(count),))
+
+        return {
+            "status": view(out.status, n, np.uint32), "n_ref": view(out.n_ref, n, np.uint32),
+            "probes": view(out.probes, n, np.uint64), "node_off": view(out.node_off, n + 1, np.uint64),
+            "extra_off": view(out.extra_off, n + 1, np.uint64),
+            "node_count": view(out.node_count, s.n_nodes, np.uint32),
+            "extra_kmer": view(out.extra_kmer, s.n_extra, np.uint64),
+            "path_off": view(out.path_off, n + 1, np.uint32),
+            "run_off": view(out.run_off, s.n_paths + 1, np.uint64),
+            "run_start": view(out.run_start, s.n_runs, np.uint32),
+            "run_len": view(out.run_len, s.n_runs, np.uint32),
+            "path_len": view(out.path_len, s.n_paths, np.uint32),
+            "path_min_cov": view(out.path_min_cov, s.n_paths, np.uint32),
+            "logical_probes": int(s.logical_probes), "table_fetches": int(s.table_fetches),
+            "n_big_tier": int(s.n_big_tier), "n_flagged": int(s.n_flagged),
+        }
+
     def fetch(self, nodes=True, paths=True):
-        """Copy results to host numpy arrays (dict)."""
+        """Copy results to host numpy arrays (dict), node k-mers rebuilt in full."""
         s = self.sizes()
         n = s.n_targets
         r = {
@@ -399,7 +437,14 @@ def _python_rows(res, t, name, seq, k, db_name):
     p0, p1 = int(res["path_off"][t]), int(res["path_off"][t + 1])
     paths = [expand_path(res, p) for p in range(p0, p1)]
     seq = seq if isinstance(seq, str) else bytes(seq).decode("ascii")
-    tr = report.TargetResult(name, seq, k, int(res["n_ref"][t]), np.asarray(res["node_kmer"][a:e]),
+    if "node_kmer" in res:
+        kmers = np.asarray(res["node_kmer"][a:e])
+    else:                                              # delivery view: own k-mers from the sequence
+        from . import kmer as km
+        x0, x1 = int(res["extra_off"][t]), int(res["extra_off"][t + 1])
+        kmers = np.concatenate([km.sliding_kmers(km.encode(seq), k)[:int(res["n_ref"][t])],
+                                np.asarray(res["extra_kmer"][x0:x1])])
+    tr = report.TargetResult(name, seq, k, int(res["n_ref"][t]), kmers,
                              np.asarray(res["node_count"][a:e]), paths,
                              np.asarray(res["path_min_cov"][p0:p1]).tolist())
     return report.target_rows(tr, db_name)
@@ -426,7 +471,10 @@ def report_rows(res, names, seqs, k, db_name, packed=None):
     for field, ctype in (("status", C.c_uint32), ("n_ref", C.c_uint32), ("probes", C.c_uint64),
                          ("node_off", C.c_uint64), ("node_kmer", C.c_uint64), ("node_count", C.c_uint32),
                          ("path_off", C.c_uint32), ("run_off", C.c_uint64), ("run_start", C.c_uint32),
-                         ("run_len", C.c_uint32), ("path_len", C.c_uint32), ("path_min_cov", C.c_uint32)):
+                         ("run_len", C.c_uint32), ("path_len", C.c_uint32), ("path_min_cov", C.c_uint32),
+                         ("extra_off", C.c_uint64), ("extra_kmer", C.c_uint64)):
+        if field not in res:
+            continue                                   # a delivery view has no node_kmer, a fetch no extra_*
         arr = np.ascontiguousarray(res[field], dtype=np.dtype(ctype))
         if arr.size == 0:
             arr = np.zeros(1, dtype=arr.dtype)

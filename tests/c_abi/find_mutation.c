@@ -51,25 +51,12 @@ int main(int argc, char** argv) {
   CHECK(km_batch_create(db, &par, 1, len + 64, &b));
   uint64_t off[2] = {0, (uint64_t)len};
   CHECK(km_batch_set_targets(b, (const uint8_t*)seq, off, 1));
-  CHECK(km_batch_run(b, KM_STAGE_WALK | KM_STAGE_GRAPH, NULL));
+  /* kernels + device-side compaction + one asynchronous D2H into the batch's pinned buffer;
+   * `out` then points into that buffer (nothing is copied or reorganised on the host) */
+  CHECK(km_batch_run(b, KM_STAGE_WALK | KM_STAGE_GRAPH | KM_RUN_DELIVER, NULL));
   km_batch_sizes_t sz;
-  CHECK(km_batch_sizes(b, &sz));
-
   km_batch_out_t out;
-  memset(&out, 0, sizeof out);
-  out.status = (uint32_t*)calloc(2, 4);
-  out.n_ref = (uint32_t*)calloc(2, 4);
-  out.probes = (uint64_t*)calloc(2, 8);
-  out.node_off = (uint64_t*)calloc(2, 8);
-  out.node_kmer = (uint64_t*)calloc(sz.n_nodes + 1, 8);
-  out.node_count = (uint32_t*)calloc(sz.n_nodes + 1, 4);
-  out.path_off = (uint32_t*)calloc(2, 4);
-  out.run_off = (uint64_t*)calloc(sz.n_paths + 1, 8);
-  out.run_start = (uint32_t*)calloc(sz.n_runs + 1, 4);
-  out.run_len = (uint32_t*)calloc(sz.n_runs + 1, 4);
-  out.path_len = (uint32_t*)calloc(sz.n_paths + 1, 4);
-  out.path_min_cov = (uint32_t*)calloc(sz.n_paths + 1, 4);
-  CHECK(km_batch_fetch(b, &out));
+  CHECK(km_batch_result(b, &out, &sz));
   if (out.status[0] != KM_T_OK) { fprintf(stderr, "target status %u\n", out.status[0]); return 3; }
 
   const char* names[1] = {argv[3]};

@@ -568,3 +568,112 @@ def test_plain_c_client(tmp_path):
         assert res.stdout.rstrip("\n").split("\n") == case["lines"][11:]
         n += 1
     assert n >= 5
+
+
+# ------------------------------------------------------------------ result delivery
+def test_delivery_view_equals_fetch():
+    """km_batch_run(.. | KM_RUN_DELIVER) + km_batch_result: the device-compacted arrays in the
+    pinned buffer equal what the copying km_batch_fetch returns, extra_kmer holds exactly the
+    walk-discovered nodes, and the native report built from the view equals the one built from
+    the fetched arrays."""
+    case = synth.make_case(n_targets=1500, length=400, n_keys=800_000, seed=4242, variant_frac=0.5,
+                           variants_per_target=(1, 3), exact_pad=False)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    seqs = [km.decode(r) for r in case["targets"]]
+    b = kmlib.Batch(db, max_targets=1500, max_total_bases=1500 * 400)
+    b.set_targets(seqs)
+    st = kmlib.stream_create(0)
+    both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    b.run(both | kmlib.KM_RUN_DELIVER, st)
+    v = {key: (np.array(val) if isinstance(val, np.ndarray) else val) for key, val in b.result().items()}
+    f = b.fetch()
+    for key in ("status", "n_ref", "probes", "node_off", "node_count", "path_off", "run_off", "run_start",
+                "run_len", "path_len", "path_min_cov"):
+        assert (v[key] == f[key]).all(), key
+    noff, xoff = v["node_off"].astype(np.int64), v["extra_off"].astype(np.int64)
+    assert int(xoff[-1]) == int(noff[-1]) - int(v["n_ref"].sum()) and int(xoff[-1]) > 1000
+    ref = km.sliding_kmers(case["targets"], 31)
+    for t in range(0, 1500, 7):
+        nr = int(v["n_ref"][t])
+        assert (f["node_kmer"][noff[t]:noff[t] + nr] == ref[t]).all()
+        assert (f["node_kmer"][noff[t] + nr:noff[t + 1]] == v["extra_kmer"][xoff[t]:xoff[t + 1]]).all()
+    # a second delivery of another run reuses the buffers (steady state of the bench)
+    b.run(both | kmlib.KM_RUN_DELIVER, st)
+    v2 = b.result()
+    for key in ("status", "node_off", "node_count", "extra_kmer", "path_off", "run_off", "run_start", "path_min_cov"):
+        assert (np.asarray(v2[key]) == v[key]).all(), key
+    names = list(case["names"])
+    rows_view = kmlib.report_rows(v2, names, seqs, 31, "mem.jf")
+    rows_fetch = kmlib.report_rows(f, names, seqs, 31, "mem.jf")
+    assert rows_view == rows_fetch
+    assert sum(len(r) > 1 for r in rows_view) > 500
+    # walk stage alone: nodes delivered, no paths
+    b.run(kmlib.KM_STAGE_WALK | kmlib.KM_RUN_DELIVER, st)
+    w = b.result()
+    assert (np.asarray(w["node_count"]) == v["node_count"]).all() and int(w["path_off"][-1]) == 0
+
+
+def test_long_targets_take_the_large_tier_one_by_one():
+    """A batch mixing 2-3 kb targets (beyond the LDS-resident tier) with ordinary ones: the long
+    ones — flagged or not — go through the large tier individually, the rest stay on the fast
+    path, every target matches the oracle; a long target with a repeated k-mer is reported."""
+    case = synth.make_case(n_targets=12, length=2600, n_keys=60_000, seed=808, variant_frac=0.5,
+                           variants_per_target=(1, 2))
+    small = synth.make_case(n_targets=40, length=300, n_keys=30_000, seed=809, variant_frac=0.4)
+    keys = np.concatenate([case["keys"], small["keys"]])
+    counts = np.concatenate([case["counts"], small["counts"]])
+    keys, first = np.unique(keys, return_index=True)
+    counts = counts[first]
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                    records={"k": 31, "canonical": True, "keys": keys, "counts": counts})
+    targets = []
+    for i in range(40):
+        targets.append((small["names"][i], km.decode(small["targets"][i])))
+        if i % 4 == 0 and i // 4 < 12:
+            targets.append((case["names"][i // 4], km.decode(case["targets"][i // 4])))
+    finder = BatchFinder(jf)
+    raw = finder.run_raw([t[1] for t in targets])
+    assert (raw["status"] == 0).all()
+    n_long = sum(len(t[1]) > 2000 for t in targets)
+    assert n_long == 10 and int((raw["path_off"][1:] > raw["path_off"][:-1]).sum()) == len(targets)
+    _compare_with_oracle(jf, cpu, targets)
+    # rows: every target prints at least its Reference row
+    rows = finder.rows(targets)
+    assert all(isinstance(r, list) and len(r) >= 1 for r in rows)
+    # a long target with a repeated k-mer among ordinary ones
+    rep = km.decode(case["targets"][0])
+    rep = rep[:1500] + rep[700:740] + rep[1500:]
+    raw = finder.run_raw([targets[0][1], rep, targets[2][1]])
+    assert raw["status"].tolist() == [kmlib.T_OK, kmlib.T_REPEAT_KMER, kmlib.T_OK]
+
+
+def test_replay_after_large_tier_and_pool_growth(monkeypatch):
+    """A captured hipGraph step must not be replayed once km_batch_sync has moved node storage
+    or enlarged the path pools; re-running the same batch does not accumulate node storage."""
+    monkeypatch.setenv("KM_TEST_SMALL_POOLS", "1")
+    case = synth.make_case(n_targets=300, length=700, n_keys=200_000, seed=77, variant_frac=0.6,
+                           variants_per_target=(1, 11), kinds=("ins", "dup", "snv"), vaf=(0.3, 0.5))
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    b = kmlib.Batch(db, max_targets=300, max_total_bases=300 * 700)
+    monkeypatch.delenv("KM_TEST_SMALL_POOLS")
+    seqs = [km.decode(r) for r in case["targets"]]
+    b.set_targets(seqs)
+    st = kmlib.stream_create(0)
+    both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    b.run(both)
+    r0 = b.fetch()
+    assert r0["n_big_tier"] > 0
+    outs = []
+    for _ in range(3):
+        b.run(both | kmlib.KM_RUN_HIPGRAPH | kmlib.KM_RUN_DELIVER, st)
+        outs.append(b.fetch())
+    for r in outs:
+        for key in ("status", "probes", "node_off", "node_kmer", "node_count", "path_off", "run_off",
+                    "run_start", "run_len", "path_min_cov"):
+            assert (r[key] == r0[key]).all(), key
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                    records={"k": 31, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+    _compare_with_oracle(jf, cpu, [(n, s_) for n, s_ in zip(case["names"][:60], seqs[:60])])
