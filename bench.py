@@ -75,13 +75,36 @@ def _cpu_work(span):
     return probes, time.perf_counter() - t0
 
 
+def usable_cores():
+    """Host cores this process may really use (affinity mask and cgroup quota, not the machine's)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(txt[0]) // int(txt[1])))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(case, n_sample):
     """The oracle (structure-faithful Python restatement of the reference path: str k-mers, one
     lookup per query, recursive extend, dense numpy Dijkstra) timed on the host: one core (the
     reference is single-threaded) and all cores (one process per core, targets sharded).  Must
     run BEFORE this process touches the GPU (it forks)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     per = max(8, n_sample // 4)
     n_all = per * cores
     n_need = min(len(case["targets"]), max(n_sample, n_all))
@@ -162,7 +185,11 @@ def oracle_check(case, views, set_ids, T, n_check):
             want = co.analyse(case["targets"][g])
             ok = int(v["status"][t]) == want["status"] == 0
             nr = int(v["n_ref"][t])
-            ok = ok and (v["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all()
+            if noff[t + 1] == noff[t]:        # lean delivery of a bare-reference target
+                ok = ok and len(want["counts"]) == nr and int(v["ref_max_cov"][t]) == int(want["counts"].max())
+                ok = ok and want["paths"] == [list(range(nr))]
+            else:
+                ok = ok and (v["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all()
             ok = ok and (v["extra_kmer"][xoff[t]:xoff[t + 1]] == want["kmers"][nr:]).all()
             ok = ok and int(v["probes"][t]) == want["probes"]
             got = [kmlib.expand_path(v, p).tolist() for p in range(poff[t], poff[t + 1])]
@@ -232,14 +259,14 @@ def main():
     case = load_case(args, T * n_fl) if rank == 0 else None
     t_gen = time.perf_counter() - t_gen
     cpu = None
+    import torch                      # before libkmgpu.so: one HIP runtime per process (torch's);
+    import torch.distributed as dist  # importing torch does not touch the GPU
     if rank == 0:
         import __graft_entry__ as ge
         ge.build()
         if not args.no_cpu and world == 1:
             cpu = cpu_baseline(case, min(args.cpu_sample, T))
 
-    import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -297,7 +324,7 @@ def main():
     # ---- workspaces: `inflight` of them, each with its own HIP stream and its OWN target set ---
     # (weak scaling: every rank steps through the same n_fl sets, rotated by its rank)
     offsets = (np.arange(T + 1, dtype=np.uint64) * np.uint64(args.length))
-    tstreams = [torch.cuda.Stream(device=dev) for _ in range(n_fl)]
+    tstreams = [kmlib.stream_create(local_rank) for _ in range(n_fl)]     # non-blocking HIP streams
     set_ids = [(q + rank) % n_fl for q in range(n_fl)]
     batches = []
     for q in range(n_fl):
@@ -309,7 +336,10 @@ def main():
     stages = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH)
     if args.hipgraph:
         stages |= kmlib.KM_RUN_HIPGRAPH
-    deliver = stages | kmlib.KM_RUN_DELIVER
+    deliver_full = stages | kmlib.KM_RUN_DELIVER
+    # lean delivery: what `km find_mutation` needs to print its TSV (km_amd.finder.BatchFinder.rows):
+    # bare-reference targets are delivered as path + min coverage + ref_max_cov, without their counts
+    deliver = deliver_full | kmlib.KM_DELIVER_LEAN
 
     def pipeline(n_steps, flags, wait):
         """n_steps steps round-robin over the workspaces; before a workspace is reused (and at
@@ -318,7 +348,7 @@ def main():
             q = i % n_fl
             if wait and i >= n_fl:
                 batches[q].wait_result()
-            batches[q].run(flags, tstreams[q].cuda_stream)
+            batches[q].run(flags, tstreams[q])
         if wait:
             for q in range(min(n_fl, n_steps)):
                 batches[q].wait_result()
@@ -347,10 +377,21 @@ def main():
             dt = float(tmax.item())
         return dt
 
+    def delivered_bytes():
+        vs = [bq.result() for bq in batches]
+        return vs, float(np.mean([sum(v[x].nbytes for x in v if isinstance(v[x], np.ndarray)) for v in vs]))
+
+    # full delivery first (every node count crosses PCIe), then the lean one that `value` reports
+    pipeline(n_fl, deliver_full, True)
+    dt_full = timed(deliver_full, True)
+    views_full, out_bytes_full = delivered_bytes()
+    check_full = None
+    if rank == 0 and args.check > 0 and not args.walk_only:
+        check_full = oracle_check(case, views_full, set_ids, T, max(n_fl, args.check // 4))
+    del views_full
+    pipeline(n_fl, deliver, True)
     dt = timed(deliver, True)
-    # the delivered bytes of one step (region A + tail) and the delivered views for the check
-    views = [bq.result() for bq in batches]
-    out_bytes = float(np.mean([sum(v[x].nbytes for x in v if isinstance(v[x], np.ndarray)) for v in views]))
+    views, out_bytes = delivered_bytes()
     check = None
     if rank == 0 and args.check > 0 and not args.walk_only:
         check = oracle_check(case, views, set_ids, T, args.check)
@@ -361,7 +402,7 @@ def main():
 
     # ---- one step at a time (no pipelining), with and without delivery -------------------------
     batch = batches[0]
-    st0 = tstreams[0].cuda_stream
+    st0 = tstreams[0]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
@@ -369,13 +410,16 @@ def main():
         batch.wait_result()
     serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
     # ---- per-kernel durations (HIP events on the launch stream), averaged over K launches
-    tm = []
-    for _ in range(args.steps):
-        batch.run(deliver & ~kmlib.KM_RUN_HIPGRAPH, st0)
-        batch.wait_result()
-        tm.append(batch.timings())
-    tm = np.mean(np.array(tm), axis=0)
-    walk_avg, graph_avg, _tot, seed_avg, pack_avg, dfs_avg, outk_avg, d2h_avg = (float(x) for x in tm)
+    def event_times(flags):
+        tm = []
+        for _ in range(args.steps):
+            batch.run(flags & ~kmlib.KM_RUN_HIPGRAPH, st0)
+            batch.wait_result()
+            tm.append(batch.timings())
+        return [float(x) for x in np.mean(np.array(tm), axis=0)]
+
+    walk_avg, graph_avg, _tot, seed_avg, pack_avg, dfs_avg, outk_avg, d2h_avg = event_times(deliver)
+    outk_full, d2h_full = event_times(deliver_full)[6:8]
 
     # ---- result fetch through the copying API (numpy arrays, node k-mers rebuilt), for scale
     t_f = time.perf_counter()
@@ -536,13 +580,20 @@ def main():
                        "stages": both_names + " + result delivery (device compaction, D2H to pinned host memory)",
                        "distinct_target_sets": n_fl,
                        "parallelism": "target-sharded x%d, table replicated (records broadcast once over RCCL)" % world},
-            "value_includes": "k_pack, k_seed, k_dfs, k_graph_pure, k_graph, k_out_scan, k_out_pack, D2H of every "
-                              "node count, walk-discovered k-mer, path and status into pinned host memory",
+            "value_includes": "k_pack, k_seed, k_dfs, k_graph_pure, k_graph, k_out_scan, k_out_pack and the D2H of the "
+                              "lean delivery into pinned host memory",
             "gprobes_per_s": world * probes_per_step / (dt / args.steps) / 1e9,
             "kernel_only": {"value": world * T / (dt_kernel / args.steps), "ms_per_step": ms_kernel,
                             "note": "same steps without result delivery (results left in HBM)"},
             "delivered_bytes_per_step": out_bytes,
             "d2h_GBs_inside_pipeline": gb(out_bytes, ms_per_step),
+            "delivery": "lean (KM_DELIVER_LEAN): statuses, probes, paths, min coverages, walk-discovered k-mers and "
+                        "the counts of every target that has them or more than one path; a bare-reference target "
+                        "(one Reference row in the TSV) is delivered as path + min coverage + max count",
+            "full_delivery": {"value": world * T / (dt_full / args.steps), "ms_per_step": dt_full / args.steps * 1e3,
+                              "delivered_bytes_per_step": out_bytes_full,
+                              "deliver_kernels_ms": outk_full, "d2h_copy_ms": d2h_full, "oracle_check": check_full,
+                              "note": "same pipeline with the counts of EVERY node crossing PCIe"},
             "logical_probes_per_step": probes_per_step,
             "table_fetches_per_step": fetches_per_step,
             "targets_in_large_tier": int(sizes[0].n_big_tier), "targets_flagged": int(sizes[0].n_flagged),
@@ -583,6 +634,13 @@ def main():
         if check is not None and not check["ok"]:
             log("ORACLE CHECK FAILED:", check)
             rc = 3
+    # release the library's device / pinned memory while the HIP runtime is still up
+    for bq in batches:
+        bq.close()
+    del batches, batch
+    for st_ in tstreams:
+        kmlib.stream_destroy(st_)
+    db.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

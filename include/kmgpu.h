@@ -125,6 +125,9 @@ typedef struct {
   uint64_t* extra_off;     /* [n_targets+1] CSR offsets into extra_kmer
                                             (extra_off[t+1]-extra_off[t] == nodes of t - n_ref[t]) */
   uint64_t* extra_kmer;    /* [n_extra]     packed k-mers of the walk-discovered nodes     */
+  uint32_t* ref_max_cov;   /* [n_targets]   bare-reference targets (the only path is the target's own
+                                            k-mer chain, no walk-discovered node): max count over
+                                            the target's k-mers; 0xFFFFFFFF for every other target */
 } km_batch_out_t;
 
 /* ---- database: replaces Jellyfish.__init__ (km/utils/Jellyfish.py:23-45) and
@@ -196,10 +199,19 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
  * waits for that copy.  Without this flag km_batch_result() / km_batch_fetch() deliver on
  * demand. */
 #define KM_RUN_DELIVER 8
+/* With KM_RUN_DELIVER: lean delivery.  A bare-reference target (ref_max_cov[t] != 0xFFFFFFFF;
+ * typically 70 % of a batch) prints one `Reference` row whose only data are path_min_cov and
+ * whether every count is 0 (km/utils/MutationFinder.py:575-648, km/utils/PathQuant.py:144-154):
+ * its node_count rows are omitted (node_off[t+1] == node_off[t]) and do not cross PCIe.  Every
+ * other target is delivered in full.  km_report_rows accepts both forms; km_batch_fetch always
+ * returns every node (re-delivering if the last delivery was lean). */
+#define KM_DELIVER_LEAN 16
 /* Launch the kernels asynchronously on `stream` (no host synchronisation unless
  * a target overflows the fast tier, in which case the large-tier pass needs one). */
 int km_batch_run(km_batch_t* b, int stages, void* stream);
 int km_batch_sync(km_batch_t* b);
+/* Sizes of the arrays km_batch_fetch fills (a full delivery; km_batch_result reports the sizes
+ * of the delivery it returns, which may be lean). */
 int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* sizes);
 int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
 /* Zero-copy variant: waits for the delivery of the last run (finishing, if some target needed

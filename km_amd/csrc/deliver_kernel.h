@@ -8,7 +8,7 @@
 //
 //   region A (offsets known on the host from n_targets alone)
 //     totals[OT_WORDS]                       sizes of the tail arrays + batch statistics
-//     status[n] n_ref[n] probes[n]           per target
+//     status[n] n_ref[n] probes[n] ref_max_cov[n]    per target
 //     node_off[n+1] extra_off[n+1] path_off[n+1]     CSR offsets
 //   tail (sub-offsets in totals[], every array 16-byte aligned)
 //     node_count[n_nodes]     counts of every node, target k-mers first          (CSR node_off)
@@ -18,11 +18,19 @@
 //     path_len[n_paths] path_min_cov[n_paths] run_off[n_paths+1]                 (CSR path_off)
 //     run_start[n_runs] run_len[n_runs]      paths, run-length encoded            (CSR run_off)
 //
+// Lean delivery (KM_DELIVER_LEAN): a target whose result is the bare reference path — no
+// walk-discovered node, one path 0..n_ref-1; 70 % of a typical batch — needs nothing but that
+// path's min coverage and the max count of its k-mers (ref_max_cov) for its TSV row
+// (km/utils/MutationFinder.py:575-648 with km/utils/PathQuant.py:144-154: rVAF nan, expression
+// min(counts) of the -1 sentinels, or nan when every count is 0); its node_count rows are then
+// omitted (node_off[t+1] == node_off[t]) and stay on the device.
+//
 // Paths of one target are sorted by their node-index sequence here (the canonical order of
 // DESIGN.md §2), nodes carry no per-target slack, nothing is reorganised on the host.
 //
-//  k_out_scan  one block: per-target sizes -> exclusive scans -> offsets, totals, statistics
-//  k_out_pack  one wave per target: copies counts / extra k-mers, ranks and emits the paths
+//  k_out_scan  one thread per target: sizes -> offsets local to a 1024-target block + block totals
+//  k_out_pack  one wave per target: adds the totals of the blocks before its own (and writes the
+//              batch totals), copies counts / extra k-mers, ranks and emits the paths
 #pragma once
 #include "device_common.h"
 #include "graph_kernel.h"
@@ -44,6 +52,7 @@ constexpr uint32_t OUT_SCAN_THREADS = 1024;
 struct OutArgs {
   uint32_t n_targets;
   uint32_t ran_graph;
+  uint32_t lean;                       // omit the node counts of bare-reference targets
   unsigned long long serial;           // stamped into totals[OT_SERIAL]: which run this delivery belongs to
   // walk / graph results
   const uint32_t* status;
@@ -53,6 +62,7 @@ struct OutArgs {
   const uint32_t* t_npaths;
   const uint32_t* t_pathbase;
   const uint32_t* t_nruns;
+  const uint32_t* t_refmax;
   const unsigned long long* probes;
   const unsigned long long* dfs_probes;
   const unsigned long long* fetches;
@@ -68,7 +78,9 @@ struct OutArgs {
   const uint32_t* r_start;
   const uint32_t* r_len;
   // scratch
-  uint64_t* run_tbase;                 // [n] first output run of each target
+  unsigned long long* loc;             // [n][4] offsets (nodes, extra, paths, runs) local to the scan block
+  uint32_t* cnt;                       // [n][4] the four sizes of each target
+  unsigned long long* blk_tot;         // [scan blocks][8] block totals: 4 sizes, probes, fetches, seed probes, needs-host
   unsigned long long* psort;           // [path pool] (source path << 32 | runs) in sorted order
   // delivery buffer
   unsigned long long* totals;
@@ -78,6 +90,7 @@ struct OutArgs {
   uint64_t* o_node_off;
   uint64_t* o_extra_off;
   uint32_t* o_path_off;
+  uint32_t* o_refmax;
   unsigned char* tail;
   uint64_t tail_cap;
 };
@@ -99,35 +112,39 @@ __device__ inline OutCounts out_counts_of(const OutArgs& a, uint32_t t, uint32_t
   if (a.ran_graph && st == T_OK && gs == T_OK) {
     c.paths = a.t_npaths[t];
     c.runs = a.t_nruns[t];
+    // lean delivery: a bare-reference target is fully described by its path record
+    // (path_min_cov) and ref_max_cov; its counts stay on the device
+    if (a.lean && c.paths == 1 && a.t_refmax[t] != NOT_BARE) c.nodes = 0;
   }
   *st_out = (st == T_OK && gs != T_OK) ? T_INTERNAL : st;
   return c;
 }
 
+// Per-target sizes -> offsets local to a block of OUT_SCAN_THREADS targets + the block's totals.
+// One thread per target: all loads of a block are in flight together.
 __global__ __launch_bounds__(OUT_SCAN_THREADS) void k_out_scan(OutArgs a) {
   __shared__ unsigned long long part[4][OUT_SCAN_THREADS / 64];
   __shared__ unsigned long long stat[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n = a.n_targets;
-  const uint32_t per = (n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS;
-  const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+  const uint32_t t = blockIdx.x * OUT_SCAN_THREADS + tid;
   if (tid < 4) stat[tid] = 0;
   __syncthreads();
-  // pass 1: this thread's totals
   unsigned long long s[4] = {0, 0, 0, 0};
   unsigned long long probes = 0, fetches = 0, seedp = 0;
   uint32_t needs = 0;
-  for (uint32_t t = lo; t < hi; ++t) {
+  if (t < n) {
     uint32_t st;
     const OutCounts c = out_counts_of(a, t, &needs, &st);
-    s[0] += c.nodes; s[1] += c.extra; s[2] += c.paths; s[3] += c.runs;
+    s[0] = c.nodes; s[1] = c.extra; s[2] = c.paths; s[3] = c.runs;
     const unsigned long long sp = a.probes[t], dp = a.dfs_probes[t];
-    seedp += sp; probes += sp + dp; fetches += a.fetches[t];
+    seedp = sp; probes = sp + dp; fetches = a.fetches[t];
     a.o_status[t] = st;
     a.o_nref[t] = a.n_ref[t];
     a.o_probes[t] = sp + dp;
+    a.o_refmax[t] = a.ran_graph ? a.t_refmax[t] : NOT_BARE;
   }
-  // exclusive scan of the four sums over the block: within the wave, then across the waves
+  // exclusive scan of the four sizes over the block: within the wave, then across the waves
   unsigned long long ex[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -160,36 +177,15 @@ __global__ __launch_bounds__(OUT_SCAN_THREADS) void k_out_scan(OutArgs a) {
     ex[q] += before;
     tot[q] = all;
   }
-  // pass 2: offsets
-  unsigned long long c0 = ex[0], c1 = ex[1], c2 = ex[2], c3 = ex[3];
-  for (uint32_t t = lo; t < hi; ++t) {
-    uint32_t st, nd = 0;
-    const OutCounts c = out_counts_of(a, t, &nd, &st);
-    a.o_node_off[t] = c0; a.o_extra_off[t] = c1; a.o_path_off[t] = (uint32_t)c2; a.run_tbase[t] = c3;
-    c0 += c.nodes; c1 += c.extra; c2 += c.paths; c3 += c.runs;
+  if (t < n) {
+    ulonglong4* L = reinterpret_cast<ulonglong4*>(a.loc) + t;
+    *L = make_ulonglong4(ex[0], ex[1], ex[2], ex[3]);
+    reinterpret_cast<uint4*>(a.cnt)[t] = make_uint4((uint32_t)s[0], (uint32_t)s[1], (uint32_t)s[2], (uint32_t)s[3]);
   }
   if (tid == 0) {
-    a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
-    unsigned long long* T = a.totals;
-    uint64_t o = 0;
-    T[OT_N_NODES] = tot[0]; T[OT_N_EXTRA] = tot[1]; T[OT_N_PATHS] = tot[2]; T[OT_N_RUNS] = tot[3];
-    T[OT_OFF_COUNT] = o;  o = out_align(o + 4 * tot[0]);
-    T[OT_OFF_EXTRA] = o;  o = out_align(o + 8 * tot[1]);
-    T[OT_OFF_PLEN] = o;   o = out_align(o + 4 * tot[2]);
-    T[OT_OFF_PMIN] = o;   o = out_align(o + 4 * tot[2]);
-    T[OT_OFF_RUNOFF] = o; o = out_align(o + 8 * (tot[2] + 1));
-    T[OT_OFF_RSTART] = o; o = out_align(o + 4 * tot[3]);
-    T[OT_OFF_RLEN] = o;   o = out_align(o + 4 * tot[3]);
-    T[OT_TAIL_BYTES] = o;
-    unsigned long long nh = stat[3];
-    if (a.ran_graph && *a.pool_overflow) nh |= 1ull;
-    if (tot[2] >= (1ull << 32)) nh |= 1ull;           // path_off is 32-bit: the host splits such batches
-    if (o > a.tail_cap) nh |= 2ull;
-    T[OT_NEEDS_HOST] = nh;
-    T[OT_PROBES] = stat[0]; T[OT_FETCHES] = stat[1]; T[OT_SEED_PROBES] = stat[2];
-    T[OT_N_FLAGGED] = *a.n_flagged;
-    T[OT_SERIAL] = a.serial;
-    for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) T[q] = 0;
+    unsigned long long* B = a.blk_tot + 8ull * blockIdx.x;
+    B[0] = tot[0]; B[1] = tot[1]; B[2] = tot[2]; B[3] = tot[3];
+    B[4] = stat[0]; B[5] = stat[1]; B[6] = stat[2]; B[7] = stat[3];
   }
 }
 
@@ -212,37 +208,88 @@ __device__ inline bool rle_less(const uint32_t* sa, const uint32_t* la, uint32_t
 __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
   const uint32_t t = blockIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long* T = a.totals;
-  if (T[OT_NEEDS_HOST]) return;          // the host finishes the batch and delivers again
-  const uint64_t n0 = a.o_node_off[t], n1 = a.o_node_off[t + 1];
-  const uint64_t e0 = a.o_extra_off[t], e1 = a.o_extra_off[t + 1];
-  const uint32_t p0 = a.o_path_off[t], p1 = a.o_path_off[t + 1];
+  const uint32_t n = a.n_targets;
+  // ---- global offsets: block totals before this target's scan block + grand totals
+  const uint32_t nblk = (n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS, myblk = t / OUT_SCAN_THREADS;
+  unsigned long long pre[4] = {0, 0, 0, 0}, tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+    const uint32_t bq = b0 + lane;
+    const ulonglong4* B = reinterpret_cast<const ulonglong4*>(a.blk_tot + 8ull * bq);
+    ulonglong4 x = make_ulonglong4(0, 0, 0, 0), y = x;
+    if (bq < nblk) { x = B[0]; y = B[1]; }
+    const bool before = bq < myblk;
+    pre[0] += before ? x.x : 0; pre[1] += before ? x.y : 0; pre[2] += before ? x.z : 0; pre[3] += before ? x.w : 0;
+    tot[0] += x.x; tot[1] += x.y; tot[2] += x.z; tot[3] += x.w;
+    tot[4] += y.x; tot[5] += y.y; tot[6] += y.z; tot[7] |= y.w;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre[q] += __shfl_xor(pre[q], o);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) tot[q] += __shfl_xor(tot[q], o);
+    tot[7] |= __shfl_xor(tot[7], o);
+  }
+  uint64_t o = 0;
+  const uint64_t off_count = o;  o = out_align(o + 4 * tot[0]);
+  const uint64_t off_extra = o;  o = out_align(o + 8 * tot[1]);
+  const uint64_t off_plen = o;   o = out_align(o + 4 * tot[2]);
+  const uint64_t off_pmin = o;   o = out_align(o + 4 * tot[2]);
+  const uint64_t off_runoff = o; o = out_align(o + 8 * (tot[2] + 1));
+  const uint64_t off_rstart = o; o = out_align(o + 4 * tot[3]);
+  const uint64_t off_rlen = o;   o = out_align(o + 4 * tot[3]);
+  unsigned long long nh = tot[7];
+  if (a.ran_graph && *a.pool_overflow) nh |= 1ull;
+  if (tot[2] >= (1ull << 32)) nh |= 1ull;            // path_off is 32-bit: the host splits such batches
+  if (o > a.tail_cap) nh |= 2ull;
+  if (t == 0 && lane == 0) {
+    unsigned long long* T = a.totals;
+    T[OT_N_NODES] = tot[0]; T[OT_N_EXTRA] = tot[1]; T[OT_N_PATHS] = tot[2]; T[OT_N_RUNS] = tot[3];
+    T[OT_TAIL_BYTES] = o; T[OT_NEEDS_HOST] = nh;
+    T[OT_OFF_COUNT] = off_count; T[OT_OFF_EXTRA] = off_extra; T[OT_OFF_PLEN] = off_plen; T[OT_OFF_PMIN] = off_pmin;
+    T[OT_OFF_RUNOFF] = off_runoff; T[OT_OFF_RSTART] = off_rstart; T[OT_OFF_RLEN] = off_rlen;
+    T[OT_PROBES] = tot[4]; T[OT_FETCHES] = tot[5]; T[OT_SEED_PROBES] = tot[6];
+    T[OT_N_FLAGGED] = *a.n_flagged;
+    T[OT_SERIAL] = a.serial;
+    for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) T[q] = 0;
+    a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
+  }
+  if (nh) return;                        // the host finishes the batch and delivers again
+  const ulonglong4 lc = reinterpret_cast<const ulonglong4*>(a.loc)[t];
+  const uint4 ct = reinterpret_cast<const uint4*>(a.cnt)[t];
+  const uint64_t n0 = pre[0] + lc.x, e0 = pre[1] + lc.y;
+  const uint32_t p0 = (uint32_t)(pre[2] + lc.z);
+  uint64_t cur = pre[3] + lc.w;          // first output run of this target
+  const uint32_t nn = ct.x, ne = ct.y, np = ct.z;
+  if (lane == 0) { a.o_node_off[t] = n0; a.o_extra_off[t] = e0; a.o_path_off[t] = p0; }
   const uint64_t nb = a.node_base[t];
-  uint32_t* o_cnt = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_COUNT]);
-  uint64_t* o_ext = reinterpret_cast<uint64_t*>(a.tail + T[OT_OFF_EXTRA]);
-  uint32_t* o_plen = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_PLEN]);
-  uint32_t* o_pmin = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_PMIN]);
-  uint64_t* o_roff = reinterpret_cast<uint64_t*>(a.tail + T[OT_OFF_RUNOFF]);
-  uint32_t* o_rs = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_RSTART]);
-  uint32_t* o_rl = reinterpret_cast<uint32_t*>(a.tail + T[OT_OFF_RLEN]);
-  // ---- nodes
-  const uint32_t nn = (uint32_t)(n1 - n0), ne = (uint32_t)(e1 - e0);
+  uint32_t* o_cnt = reinterpret_cast<uint32_t*>(a.tail + off_count);
+  uint64_t* o_ext = reinterpret_cast<uint64_t*>(a.tail + off_extra);
+  uint32_t* o_plen = reinterpret_cast<uint32_t*>(a.tail + off_plen);
+  uint32_t* o_pmin = reinterpret_cast<uint32_t*>(a.tail + off_pmin);
+  uint64_t* o_roff = reinterpret_cast<uint64_t*>(a.tail + off_runoff);
+  uint32_t* o_rs = reinterpret_cast<uint32_t*>(a.tail + off_rstart);
+  uint32_t* o_rl = reinterpret_cast<uint32_t*>(a.tail + off_rlen);
+  // ---- nodes (four independent loads per lane in flight)
   {
     const uint32_t* src = a.node_cnt + nb;
     uint32_t* dst = o_cnt + n0;
-    for (uint32_t i = lane; i < nn; i += 64) dst[i] = src[i];
+    for (uint32_t i0 = lane; i0 < nn; i0 += 256) {
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) v[u] = (i0 + 64 * u < nn) ? src[i0 + 64 * u] : 0u;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) if (i0 + 64 * u < nn) dst[i0 + 64 * u] = v[u];
+    }
   }
   if (ne) {
     const uint64_t* src = a.node_kmer + nb + (nn - ne);
     uint64_t* dst = o_ext + e0;
     for (uint32_t i = lane; i < ne; i += 64) dst[i] = src[i];
   }
-  if (t + 1 == a.n_targets && lane == 0) o_roff[T[OT_N_PATHS]] = T[OT_N_RUNS];
+  if (t + 1 == n && lane == 0) o_roff[tot[2]] = tot[3];
   // ---- paths, sorted by index sequence
-  const uint32_t np = p1 - p0;
   if (np == 0) return;
   const uint32_t pb = a.t_pathbase[t];
-  uint64_t cur = a.run_tbase[t];
   if (np == 1) {
     const uint32_t nr = a.p_nruns[pb];
     const uint64_t rb = a.p_runbase[pb];

@@ -48,6 +48,7 @@ namespace kmd {
 constexpr uint32_t GRAPH_THREADS = 256;
 constexpr uint32_t POOL_GROUPS = 64;       // bump-allocation counters, one 128-B line each
 constexpr uint32_t POOL_CTR_STRIDE = 16;   // uint64 per group
+constexpr uint32_t NOT_BARE = 0xFFFFFFFFu;
 
 struct GraphArgs {
   int k;
@@ -74,6 +75,8 @@ struct GraphArgs {
   uint32_t* t_npaths;        // per target
   uint32_t* t_pathbase;      // per target: first path record
   uint32_t* t_nruns;         // per target: run records over all its paths
+  uint32_t* t_refmax;        // per target: max count over its own k-mers when the result is the bare
+                             // reference path (decided by the pure-chain tests), else NOT_BARE
   // Pools are split into POOL_GROUPS equal regions (group = target & 63) so that the
   // bump-allocation atomics of different targets rarely share an address.
   // counters[g*16+0] paths used in group g, [g*16+1] runs used, counters[64*16] overflow flag
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t h_status = a.status[t], h_tflag = a.tflag[t];   // header words requested together
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
+  if (tid == 0) a.t_refmax[t] = NOT_BARE;      // every target passes here before k_graph sees it
   if (h_status != T_OK) {
     if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: LDS runs its operations in order
   uint32_t not_pure = 0;
-  uint32_t mincov = 0xFFFFFFFFu;
+  uint32_t mincov = 0xFFFFFFFFu, maxcov = 0;
   auto insert = [&](uint64_t key) {
     uint32_t fp = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
     fp ^= fp >> 16;
@@ -195,13 +199,17 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
       if (j0 + u * NT > n_ref) break;
       insert(kk[u]);
       mincov = cc[u] < mincov ? cc[u] : mincov;
+      if (j0 + u * NT < n_ref) maxcov = cc[u] > maxcov ? cc[u] : maxcov;
     }
   }
   if (__any((int)not_pure)) {
     if (tid == 0) a.need_full[t] = 1;
     return;
   }
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov;
+    const uint32_t om = __shfl_xor(maxcov, o); maxcov = om > maxcov ? om : maxcov;
+  }
   if (lane == 0) {
     const uint32_t pg = t % POOL_GROUPS;
     const uint64_t pg_paths = a.path_pool / POOL_GROUPS, pg_runs = a.run_pool / POOL_GROUPS;
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
       a.r_start[ri] = 0; a.r_len[ri] = n_ref;
       a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
       a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi; a.t_nruns[t] = 1;
+      a.t_refmax[t] = maxcov;
     }
     a.need_full[t] = 0;
     a.g_status[t] = T_OK;
@@ -354,9 +363,16 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     }
     if (!__syncthreads_or((int)not_pure)) {
       if (wave == 0) {
-        uint32_t mincov = 0xFFFFFFFFu;
-        for (uint32_t q = lane; q < n_ref; q += 64) { const uint32_t c = ncnt[q]; mincov = c < mincov ? c : mincov; }
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov; }
+        uint32_t mincov = 0xFFFFFFFFu, maxcov = 0;
+        for (uint32_t q = lane; q < n_ref; q += 64) {
+          const uint32_t c = ncnt[q];
+          mincov = c < mincov ? c : mincov;
+          maxcov = c > maxcov ? c : maxcov;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = __shfl_xor(mincov, o); mincov = other < mincov ? other : mincov;
+          const uint32_t om = __shfl_xor(maxcov, o); maxcov = om > maxcov ? om : maxcov;
+        }
         if (lane == 0) {
           const unsigned long long pl = atomicAdd(&ctr[0], 1ull);
           const unsigned long long rl = atomicAdd(&ctr[1], 1ull);
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
             a.r_start[ri] = 0; a.r_len[ri] = n_ref;
             a.p_target[pi] = t; a.p_runbase[pi] = ri; a.p_nruns[pi] = 1; a.p_len[pi] = n_ref; a.p_mincov[pi] = mincov;
             a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi; a.t_nruns[t] = 1;
+            a.t_refmax[t] = maxcov;
           }
           a.g_status[t] = T_OK;
         }

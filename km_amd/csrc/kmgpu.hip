@@ -605,7 +605,7 @@ constexpr uint32_t FAST_BCAP_MAX = 512;       // branch frames the fast tier kee
 constexpr uint32_t FAST_FCAP_MAX = 4096;      // stack frames per target in the fast tier's scratch
 
 // Region A of the delivery buffer (deliver_kernel.h): offsets from n_targets alone.
-struct OutLayout { uint64_t totals, status, n_ref, probes, node_off, extra_off, path_off, a_bytes; };
+struct OutLayout { uint64_t totals, status, n_ref, probes, node_off, extra_off, path_off, ref_max, a_bytes; };
 OutLayout out_layout(uint32_t n) {
   auto al = [](uint64_t v) { return (v + 63) & ~63ull; };
   OutLayout L;
@@ -617,6 +617,7 @@ OutLayout out_layout(uint32_t n) {
   L.node_off = o;  o = al(o + 8ull * ((uint64_t)n + 1));
   L.extra_off = o; o = al(o + 8ull * ((uint64_t)n + 1));
   L.path_off = o;  o = al(o + 4ull * ((uint64_t)n + 1));
+  L.ref_max = o;   o = al(o + 4ull * n);
   L.a_bytes = o;
   return L;
 }
@@ -658,7 +659,7 @@ struct km_batch {
   std::vector<uint32_t> h_node_cap, h_node_cap0;
   uint64_t node_pool0 = 0;
   bool layout_moved = false;           // the large tier re-homed some targets: restore before the next run
-  DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full, d_t_nruns;
+  DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full, d_t_nruns, d_t_refmax;
   hipStream_t side = nullptr;          // overlaps k_graph_pure with k_dfs
   hipEvent_t ev_seed_done = nullptr, ev_pure_done = nullptr;       // eager fork / join
   hipEvent_t ev_cap_seed = nullptr, ev_cap_pure = nullptr;         // fork / join inside a captured step
@@ -679,13 +680,14 @@ struct km_batch {
   DevBuf<uint64_t> d_p_runbase;
   uint64_t path_pool = 0, run_pool = 0;
   // delivery (deliver_kernel.h): device buffer in its final host layout + its pinned host twin
-  DevBuf<uint64_t> d_run_tbase;
-  DevBuf<unsigned long long> d_psort;
+  DevBuf<unsigned long long> d_loc, d_blk_tot, d_psort;
+  DevBuf<uint32_t> d_cnt4;
   unsigned char* d_out = nullptr;
   unsigned char* h_out = nullptr;
   uint64_t out_cap = 0;
   hipEvent_t ev_out = nullptr;
   bool deliver_pending = false, result_ready = false;
+  bool lean = false;                  // the pending / ready delivery omits bare-reference node counts
   uint64_t copied_tail = 0, tail_guess = 0;
   unsigned long long serial = 0;
   std::vector<uint64_t> h_packed;     // km_batch_fetch: packed targets, when node_kmer is asked for
@@ -767,7 +769,10 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_pathbase.alloc(max_targets));
   A(b->d_need_full.alloc(max_targets));
   A(b->d_t_nruns.alloc(max_targets));
-  A(b->d_run_tbase.alloc((uint64_t)max_targets + 1));
+  A(b->d_t_refmax.alloc(max_targets));
+  A(b->d_loc.alloc(4ull * max_targets));
+  A(b->d_cnt4.alloc(4ull * max_targets));
+  A(b->d_blk_tot.alloc(8ull * (max_targets / OUT_SCAN_THREADS + 1)));
   A(b->d_probes.alloc(max_targets));
   A(b->d_fetches.alloc(max_targets));
   const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA;
@@ -825,8 +830,8 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_tflag.release(); b->d_flagged.release(); b->d_nflagged.release(); b->d_dfs_probes.release();
   b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
-  b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release(); b->d_t_nruns.release();
-  b->d_run_tbase.release(); b->d_psort.release();
+  b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release(); b->d_t_nruns.release(); b->d_t_refmax.release();
+  b->d_loc.release(); b->d_cnt4.release(); b->d_blk_tot.release(); b->d_psort.release();
   if (b->side) (void)hipStreamDestroy(b->side);
   if (b->ev_seed_done) (void)hipEventDestroy(b->ev_seed_done);
   if (b->ev_pure_done) (void)hipEventDestroy(b->ev_pure_done);
@@ -1007,6 +1012,7 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.t_npaths = b->d_npaths.p;
   g.t_pathbase = b->d_pathbase.p;
   g.t_nruns = b->d_t_nruns.p;
+  g.t_refmax = b->d_t_refmax.p;
   g.counters = b->d_counters.p;
   g.path_pool = b->path_pool;
   g.run_pool = b->run_pool;
@@ -1096,8 +1102,9 @@ static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
 
 // Compaction kernels + ONE asynchronous copy of region A and the expected part of the tail into
 // the pinned twin; km_batch_result() waits for ev_out and fetches what the guess left behind.
-static int enqueue_deliver(km_batch* b, hipStream_t st) {
+static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   const uint32_t n = b->n_targets;
+  b->lean = lean;
   const OutLayout L = out_layout(n);
   b->result_ready = false;
   if (n == 0) {
@@ -1113,9 +1120,11 @@ static int enqueue_deliver(km_batch* b, hipStream_t st) {
   memset(&oa, 0, sizeof oa);
   oa.n_targets = n;
   oa.ran_graph = (b->ran_graph && b->graph_mode == 0) ? 1u : 0u;
+  oa.lean = lean ? 1u : 0u;
   oa.serial = ++b->serial;
   oa.status = b->d_status.p; oa.g_status = b->d_gstatus.p; oa.n_nodes = b->d_n_nodes.p; oa.n_ref = b->d_n_ref.p;
   oa.t_npaths = b->d_npaths.p; oa.t_pathbase = b->d_pathbase.p; oa.t_nruns = b->d_t_nruns.p;
+  oa.t_refmax = b->d_t_refmax.p;
   oa.probes = reinterpret_cast<unsigned long long*>(b->d_probes.p);
   oa.dfs_probes = b->d_dfs_probes.p;
   oa.fetches = reinterpret_cast<unsigned long long*>(b->d_fetches.p);
@@ -1124,7 +1133,7 @@ static int enqueue_deliver(km_batch* b, hipStream_t st) {
   oa.node_base = b->d_node_base.p; oa.node_kmer = b->d_node_kmer.p; oa.node_cnt = b->d_node_cnt.p;
   oa.p_runbase = b->d_p_runbase.p; oa.p_nruns = b->d_p_nruns.p; oa.p_len = b->d_p_len.p;
   oa.p_mincov = b->d_p_mincov.p; oa.r_start = b->d_r_start.p; oa.r_len = b->d_r_len.p;
-  oa.run_tbase = b->d_run_tbase.p; oa.psort = b->d_psort.p;
+  oa.loc = b->d_loc.p; oa.cnt = b->d_cnt4.p; oa.blk_tot = b->d_blk_tot.p; oa.psort = b->d_psort.p;
   oa.totals = reinterpret_cast<unsigned long long*>(b->d_out + L.totals);
   oa.o_status = reinterpret_cast<uint32_t*>(b->d_out + L.status);
   oa.o_nref = reinterpret_cast<uint32_t*>(b->d_out + L.n_ref);
@@ -1132,9 +1141,10 @@ static int enqueue_deliver(km_batch* b, hipStream_t st) {
   oa.o_node_off = reinterpret_cast<uint64_t*>(b->d_out + L.node_off);
   oa.o_extra_off = reinterpret_cast<uint64_t*>(b->d_out + L.extra_off);
   oa.o_path_off = reinterpret_cast<uint32_t*>(b->d_out + L.path_off);
+  oa.o_refmax = reinterpret_cast<uint32_t*>(b->d_out + L.ref_max);
   oa.tail = b->d_out + L.a_bytes;
   oa.tail_cap = b->out_cap - L.a_bytes;
-  hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(OUT_SCAN_THREADS), 0, st, oa);
+  hipLaunchKernelGGL(k_out_scan, dim3((n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS), dim3(OUT_SCAN_THREADS), 0, st, oa);
   hipLaunchKernelGGL(k_out_pack, dim3(n), dim3(64), 0, st, oa);
   HIPCHK(hipGetLastError());
   if (b->timed) HIPCHK(hipEventRecord(b->ev[5], st));
@@ -1170,6 +1180,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   b->last_stream = st;
   const bool want_graph = (stages & KM_RUN_HIPGRAPH) != 0;
   const bool want_deliver = (stages & KM_RUN_DELIVER) != 0;
+  const bool want_lean = (stages & KM_DELIVER_LEAN) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
   b->deliver_pending = b->result_ready = false;
   b->timed_deliver = false;
@@ -1179,7 +1190,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     b->ran_graph = (stages & KM_STAGE_GRAPH) != 0;
     b->graph_mode = b->ran_graph ? 0 : 1;
     b->synced = true;
-    return want_deliver ? enqueue_deliver(b, st) : KM_OK;
+    return want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
   }
   {
     int rc = restore_layout(b, st);
@@ -1191,7 +1202,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     b->ran_graph = true;
     b->synced = false;
     b->timed = false;
-    return want_deliver ? enqueue_deliver(b, st) : KM_OK;
+    return want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
   }
 
   b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
@@ -1269,7 +1280,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
   }
   b->synced = false;
-  return want_deliver ? enqueue_deliver(b, st) : KM_OK;
+  return want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
 }
 
 static int pull_status(km_batch* b, hipStream_t st) {
@@ -1488,15 +1499,20 @@ extern "C" int km_batch_sync(km_batch_t* b) {
 }
 
 // Results of the last run in the pinned delivery buffer (delivering now if the run did not).
-static int finish_result(km_batch* b) {
+// `need_full`: a lean delivery (pending or ready) is replaced by a full one.
+static int finish_result(km_batch* b, bool need_full) {
   if (!b->ran_walk) return fail(KM_E_STATE, "nothing has run yet");
-  if (b->result_ready) return KM_OK;
+  if (b->result_ready && !(need_full && b->lean)) return KM_OK;
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = b->last_stream;
+  if (need_full && b->lean && (b->deliver_pending || b->result_ready)) {
+    HIPCHK(hipEventSynchronize(b->ev_out));
+    b->deliver_pending = b->result_ready = false;
+  }
   if (!b->deliver_pending) {
     int rc = km_batch_sync(b);
     if (rc != KM_OK) return rc;
-    rc = enqueue_deliver(b, st);
+    rc = enqueue_deliver(b, st, false);
     if (rc != KM_OK) return rc;
   }
   const OutLayout L = out_layout(b->n_targets);
@@ -1523,7 +1539,7 @@ static int finish_result(km_batch* b) {
       if (rc != KM_OK) return rc;
     }
     T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
-    int rc = enqueue_deliver(b, st);
+    int rc = enqueue_deliver(b, st, b->lean);
     if (rc != KM_OK) return rc;
   }
   const uint64_t tail = T[OT_TAIL_BYTES];
@@ -1548,6 +1564,7 @@ static void view_of_result(const km_batch* b, km_batch_out_t* v) {
   v->node_off = reinterpret_cast<uint64_t*>(h + L.node_off);
   v->extra_off = reinterpret_cast<uint64_t*>(h + L.extra_off);
   v->path_off = reinterpret_cast<uint32_t*>(h + L.path_off);
+  v->ref_max_cov = reinterpret_cast<uint32_t*>(h + L.ref_max);
   v->node_count = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_COUNT]);
   v->extra_kmer = reinterpret_cast<uint64_t*>(tail + T[OT_OFF_EXTRA]);
   v->path_len = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_PLEN]);
@@ -1574,7 +1591,7 @@ static void sizes_of_result(const km_batch* b, km_batch_sizes_t* s) {
 
 extern "C" int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes) {
   if (!b) return fail(KM_E_ARG, "null argument");
-  int rc = finish_result(b);
+  int rc = finish_result(b, false);
   if (rc != KM_OK) return rc;
   if (view) view_of_result(b, view);
   if (sizes) sizes_of_result(b, sizes);
@@ -1608,7 +1625,10 @@ extern "C" int km_batch_timings(km_batch_t* b, float* ms8) {
 
 extern "C" int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* s) {
   if (!b || !s) return fail(KM_E_ARG, "null argument");
-  return km_batch_result(b, nullptr, s);
+  int rc = finish_result(b, true);          // the sizes km_batch_fetch fills: a full delivery
+  if (rc != KM_OK) return rc;
+  sizes_of_result(b, s);
+  return KM_OK;
 }
 
 // Copying variant of km_batch_result: fills caller-allocated arrays (sizes from km_batch_sizes).
@@ -1616,7 +1636,7 @@ extern "C" int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* s) {
 // the walk-discovered ones from extra_kmer.
 extern "C" int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out) {
   if (!b || !out) return fail(KM_E_ARG, "null argument");
-  int rc = finish_result(b);
+  int rc = finish_result(b, true);          // the copying API always returns every node
   if (rc != KM_OK) return rc;
   km_batch_out_t v;
   km_batch_sizes_t s;
@@ -1632,6 +1652,7 @@ extern "C" int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out) {
   if (out->node_count) memcpy(out->node_count, v.node_count, 4 * s.n_nodes);
   if (out->extra_kmer) memcpy(out->extra_kmer, v.extra_kmer, 8 * s.n_extra);
   if (out->path_off) memcpy(out->path_off, v.path_off, 4ull * (n + 1));
+  if (out->ref_max_cov) memcpy(out->ref_max_cov, v.ref_max_cov, 4ull * n);
   if (out->run_off) memcpy(out->run_off, v.run_off, 8ull * (s.n_paths + 1));
   if (out->run_start) memcpy(out->run_start, v.run_start, 4 * s.n_runs);
   if (out->run_len) memcpy(out->run_len, v.run_len, 4 * s.n_runs);

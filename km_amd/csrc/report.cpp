@@ -43,7 +43,8 @@ struct Target {
   int64_t n_ref;
   const uint64_t* kmers;    // all nodes, or NULL: then node i < n_ref is the k-mer at base i of seq
   const uint64_t* extra;    // ... and node n_ref + j is extra[j]
-  const uint32_t* counts;
+  const uint32_t* counts;   // NULL for a bare-reference target delivered lean: only ref_max is known
+  uint32_t ref_max;         // max count over the target's own k-mers (bare-reference targets)
   int64_t n_nodes;
   std::vector<Path> paths;
   std::vector<uint32_t> min_cov;
@@ -427,6 +428,18 @@ void cluster_groups(const std::vector<Split>& diffs, std::vector<Group>* out) {
 int target_rows(const Target& t, const char* db, std::vector<std::string>* rows_out) {
   const int k = t.k;
   const int64_t n_ref = t.n_ref, n_total = t.n_nodes + 2;
+  if (!t.counts) {
+    // lean delivery of a bare-reference target: its single row needs the path's min coverage and
+    // whether every count is 0 (then PathQuant's rVAF aliases coef and both print nan)
+    const double nan0 = std::numeric_limits<double>::quiet_NaN();
+    const double expr0 = t.ref_max == 0 ? nan0 : -1.0;
+    const std::string ref_seq0(t.seq, std::min<size_t>(t.seq_len, (size_t)(n_ref + k - 1)));
+    rows_out->clear();
+    if (t.paths.size() != 1 || !is_reference(t.paths[0], n_ref)) return 3;
+    rows_out->push_back(format_row(db, t.name, "Reference\t", nan0, expr0, t.min_cov[0], 0, ref_seq0, expr0,
+                                   ref_seq0, "vs_ref"));
+    return 0;
+  }
   std::vector<float> counts((size_t)n_total);
   for (int64_t i = 0; i < t.n_nodes; ++i) counts[(size_t)i] = (float)t.counts[i];
   counts[(size_t)n_total - 2] = counts[(size_t)n_total - 1] = -1.0f;
@@ -548,6 +561,13 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
           t.extra = r.node_kmer ? nullptr : r.extra_kmer + r.extra_off[ti];
           t.counts = r.node_count + r.node_off[ti];
           t.n_nodes = (int64_t)(r.node_off[ti + 1] - r.node_off[ti]);
+          t.ref_max = 0;
+          if (t.n_nodes == 0 && t.n_ref > 0) {
+            if (!r.ref_max_cov || r.ref_max_cov[ti] == 0xFFFFFFFFu) { err[ti] = 3; continue; }
+            t.counts = nullptr;                      // bare-reference target, delivered lean
+            t.ref_max = r.ref_max_cov[ti];
+            t.n_nodes = t.n_ref;
+          }
           const uint32_t p0 = r.path_off[ti], p1 = r.path_off[ti + 1];
           t.paths.resize(p1 - p0);
           t.min_cov.assign(r.path_min_cov + p0, r.path_min_cov + p1);

@@ -80,7 +80,7 @@ class BatchFinder:
         b.set_targets_packed(*packed)
         # kernels + device-side compaction + one asynchronous D2H into the batch's pinned buffer;
         # `raw` are views into that buffer (no host reorganisation, no copy)
-        b.run(_lib.KM_STAGE_WALK | _lib.KM_STAGE_GRAPH | _lib.KM_RUN_DELIVER)
+        b.run(_lib.KM_STAGE_WALK | _lib.KM_STAGE_GRAPH | _lib.KM_RUN_DELIVER | _lib.KM_DELIVER_LEAN)
         raw = b.result()
         self._raise_input_errors(raw, names, seqs)
         out = _lib.report_rows(raw, names, seqs, self.jf.k, self.jf.filename if db_name is None else db_name,

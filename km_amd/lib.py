@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkmgpu.so")
 
 KM_OK = 0
-KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER = 1, 2, 4, 8
+KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER, KM_DELIVER_LEAN = 1, 2, 4, 8, 16
 T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 
 # every symbol include/kmgpu.h declares (tests check the library exports them all)
@@ -61,7 +61,8 @@ class BatchOut(C.Structure):
     _fields_ = [("status", _P32), ("aux", _P32), ("n_ref", _P32), ("probes", _P64),
                 ("node_off", _P64), ("node_kmer", _P64), ("node_count", _P32),
                 ("path_off", _P32), ("run_off", _P64), ("run_start", _P32), ("run_len", _P32),
-                ("path_len", _P32), ("path_min_cov", _P32), ("extra_off", _P64), ("extra_kmer", _P64)]
+                ("path_len", _P32), ("path_min_cov", _P32), ("extra_off", _P64), ("extra_kmer", _P64),
+                ("ref_max_cov", _P32)]
 
 
 class ReportIn(C.Structure):
@@ -358,6 +359,7 @@ class Batch:
             "status": view(out.status, n, np.uint32), "n_ref": view(out.n_ref, n, np.uint32),
             "probes": view(out.probes, n, np.uint64), "node_off": view(out.node_off, n + 1, np.uint64),
             "extra_off": view(out.extra_off, n + 1, np.uint64),
+            "ref_max_cov": view(out.ref_max_cov, n, np.uint32),
             "node_count": view(out.node_count, s.n_nodes, np.uint32),
             "extra_kmer": view(out.extra_kmer, s.n_extra, np.uint64),
             "path_off": view(out.path_off, n + 1, np.uint32),
@@ -472,7 +474,7 @@ def report_rows(res, names, seqs, k, db_name, packed=None):
                          ("node_off", C.c_uint64), ("node_kmer", C.c_uint64), ("node_count", C.c_uint32),
                          ("path_off", C.c_uint32), ("run_off", C.c_uint64), ("run_start", C.c_uint32),
                          ("run_len", C.c_uint32), ("path_len", C.c_uint32), ("path_min_cov", C.c_uint32),
-                         ("extra_off", C.c_uint64), ("extra_kmer", C.c_uint64)):
+                         ("extra_off", C.c_uint64), ("extra_kmer", C.c_uint64), ("ref_max_cov", C.c_uint32)):
         if field not in res:
             continue                                   # a delivery view has no node_kmer, a fetch no extra_*
         arr = np.ascontiguousarray(res[field], dtype=np.dtype(ctype))

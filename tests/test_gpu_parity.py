@@ -607,6 +607,26 @@ def test_delivery_view_equals_fetch():
     rows_fetch = kmlib.report_rows(f, names, seqs, 31, "mem.jf")
     assert rows_view == rows_fetch
     assert sum(len(r) > 1 for r in rows_view) > 500
+    # lean delivery: bare-reference targets keep their counts on the device; same TSV rows
+    b.run(both | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN, st)
+    ln = {key: (np.array(val) if isinstance(val, np.ndarray) else val) for key, val in b.result().items()}
+    lnoff = ln["node_off"].astype(np.int64)
+    bare = ln["ref_max_cov"] != 0xFFFFFFFF
+    assert 300 < int(bare.sum()) < 1200
+    assert (np.diff(lnoff)[bare] == 0).all() and (np.diff(lnoff)[~bare] == np.diff(noff)[~bare]).all()
+    assert len(ln["node_count"]) < len(v["node_count"]) * 0.8
+    for t in np.nonzero(bare)[0][::5]:
+        assert int(ln["ref_max_cov"][t]) == int(v["node_count"][noff[t]:noff[t + 1]].max())
+        assert int(v["path_off"][t + 1]) - int(v["path_off"][t]) == 1
+    for t in np.nonzero(~bare)[0][::5]:
+        assert (ln["node_count"][lnoff[t]:lnoff[t + 1]] == v["node_count"][noff[t]:noff[t + 1]]).all()
+    for key in ("status", "n_ref", "probes", "extra_off", "extra_kmer", "path_off", "run_off", "run_start",
+                "run_len", "path_len", "path_min_cov"):
+        assert (ln[key] == v[key]).all(), key
+    assert (ln["ref_max_cov"] == v2["ref_max_cov"]).all()
+    assert kmlib.report_rows(ln, names, seqs, 31, "mem.jf") == rows_fetch
+    f2 = b.fetch()                                  # the copying API re-delivers in full
+    assert (f2["node_count"] == f["node_count"]).all() and (f2["node_off"] == f["node_off"]).all()
     # walk stage alone: nodes delivered, no paths
     b.run(kmlib.KM_STAGE_WALK | kmlib.KM_RUN_DELIVER, st)
     w = b.result()

@@ -168,3 +168,64 @@ def test_native_rows_rank_deficient_cluster_fit():
     blocks = kmlib.report_rows(_raw_from_oracle(results), names, seqs, k, "soak.jf")
     for res, seq, got in zip(results, seqs, blocks):
         assert got == _python_rows(res, seq, "soak.jf"), res["name"]
+
+
+def _as_delivery(raw, lean):
+    """The same results in the form km_batch_result delivers them: no node_kmer (the target's own
+    k-mers come from its sequence), walk-discovered k-mers in extra_kmer, ref_max_cov, and — lean —
+    no node_count rows for bare-reference targets."""
+    n = len(raw["status"])
+    noff, poff = raw["node_off"].astype(np.int64), raw["path_off"].astype(np.int64)
+    counts, extra, node_off, extra_off, ref_max = [], [], [0], [0], []
+    for t in range(n):
+        nr = int(raw["n_ref"][t])
+        c = raw["node_count"][noff[t]:noff[t + 1]]
+        kms = raw["node_kmer"][noff[t]:noff[t + 1]]
+        paths = [kmlib.expand_path(raw, p).tolist() for p in range(poff[t], poff[t + 1])]
+        bare = len(c) == nr and paths == [list(range(nr))]
+        ref_max.append(int(c[:nr].max()) if bare else 0xFFFFFFFF)
+        if not (lean and bare):
+            counts += c.tolist()
+        extra += kms[nr:].tolist()
+        node_off.append(len(counts))
+        extra_off.append(len(extra))
+    out = {k_: v for k_, v in raw.items() if k_ not in ("node_kmer", "node_count", "node_off")}
+    out.update(node_off=np.array(node_off, np.uint64), node_count=np.array(counts, np.uint32),
+               extra_off=np.array(extra_off, np.uint64), extra_kmer=np.array(extra, np.uint64),
+               ref_max_cov=np.array(ref_max, np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("name", ["cfg4_small", "stress", "lowcov", "k21"])
+def test_native_rows_from_delivery_views(name, tmp_path):
+    """km_report_rows over the delivered forms (full and lean) == over the fetched arrays."""
+    spec = next(s_ for s_ in synth.GOLDEN_SPECS if s_["name"] == name)
+    fas, dbp, _meta = synth.write_case(str(tmp_path), **spec)
+    db = ko.KmerDB(dbp, cutoff=0.05, n_cutoff=5)
+    names, seqs, results = [], [], []
+    for f in fas:
+        nm = os.path.splitext(os.path.basename(f))[0]
+        seq = ko.read_fasta_concat(f)
+        names.append(nm); seqs.append(seq)
+        results.append(ko.analyse_target(seq, nm, db))
+    raw = _raw_from_oracle(results)
+    want = kmlib.report_rows(raw, names, seqs, db.k, dbp)
+    full = _as_delivery(raw, lean=False)
+    lean = _as_delivery(raw, lean=True)
+    assert len(lean["node_count"]) <= len(full["node_count"]) and (name != "cfg4_small" or len(lean["node_count"]) < 0.6 * len(full["node_count"]))
+    assert kmlib.report_rows(full, names, seqs, db.k, dbp) == want
+    assert kmlib.report_rows(lean, names, seqs, db.k, dbp) == want
+
+
+def test_native_rows_lean_zero_coverage_reference():
+    """A bare-reference target whose k-mers all have count 0 prints nan expression (rVAF aliases
+    coef in km/utils/PathQuant.py:144-154); ref_max_cov carries that through a lean delivery."""
+    k = 31
+    seq = km.decode(np.random.default_rng(5).integers(0, 4, size=80, dtype=np.uint8))
+    db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": k, "canonical": True,
+                                                            "keys": np.zeros(0, np.uint64), "counts": np.zeros(0, np.uint32)})
+    res = ko.analyse_target(seq, "zero", db)
+    raw = _raw_from_oracle([res])
+    want = kmlib.report_rows(raw, ["zero"], [seq], k, "mem.jf")
+    assert "nan" in want[0][0].split("\t")[5]
+    assert kmlib.report_rows(_as_delivery(raw, True), ["zero"], [seq], k, "mem.jf") == want
