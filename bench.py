@@ -413,7 +413,7 @@ def main():
     def event_times(flags):
         tm = []
         for _ in range(args.steps):
-            batch.run(flags & ~kmlib.KM_RUN_HIPGRAPH, st0)
+            batch.run((flags & ~kmlib.KM_RUN_HIPGRAPH) | kmlib.KM_RUN_TIMED, st0)
             batch.wait_result()
             tm.append(batch.timings())
         return [float(x) for x in np.mean(np.array(tm), axis=0)]

@@ -206,6 +206,8 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
  * other target is delivered in full.  km_report_rows accepts both forms; km_batch_fetch always
  * returns every node (re-delivering if the last delivery was lean). */
 #define KM_DELIVER_LEAN 16
+/* Record the HIP events km_batch_timings reads (seven event records per run; off by default). */
+#define KM_RUN_TIMED 32
 /* Launch the kernels asynchronously on `stream` (no host synchronisation unless
  * a target overflows the fast tier, in which case the large-tier pass needs one). */
 int km_batch_run(km_batch_t* b, int stages, void* stream);
@@ -220,7 +222,8 @@ int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
  * Either output may be NULL.  This is what `km find_mutation` needs per target
  * (km/tools/find_mutation.py:49-58) and what km_report_rows consumes. */
 int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes);
-/* Durations (ms) of the last run measured with HIP events on the launch stream:
+/* Durations (ms) of the last run (it must have carried KM_RUN_TIMED; zeros otherwise) measured
+ * with HIP events on the launch stream:
  * [0] walk stage (k_pack + k_seed + k_dfs), [1] graph stage, [2] walk + graph,
  * [3] k_seed, [4] k_pack, [5] k_dfs, [6] the delivery kernels (k_out_scan + k_out_pack),
  * [7] the device-to-host copy ([6], [7]: 0 unless the run carried KM_RUN_DELIVER). */

@@ -1134,22 +1134,32 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.p_runbase = b->d_p_runbase.p; oa.p_nruns = b->d_p_nruns.p; oa.p_len = b->d_p_len.p;
   oa.p_mincov = b->d_p_mincov.p; oa.r_start = b->d_r_start.p; oa.r_len = b->d_r_len.p;
   oa.loc = b->d_loc.p; oa.cnt = b->d_cnt4.p; oa.blk_tot = b->d_blk_tot.p; oa.psort = b->d_psort.p;
-  oa.totals = reinterpret_cast<unsigned long long*>(b->d_out + L.totals);
-  oa.o_status = reinterpret_cast<uint32_t*>(b->d_out + L.status);
-  oa.o_nref = reinterpret_cast<uint32_t*>(b->d_out + L.n_ref);
-  oa.o_probes = reinterpret_cast<uint64_t*>(b->d_out + L.probes);
-  oa.o_node_off = reinterpret_cast<uint64_t*>(b->d_out + L.node_off);
-  oa.o_extra_off = reinterpret_cast<uint64_t*>(b->d_out + L.extra_off);
-  oa.o_path_off = reinterpret_cast<uint32_t*>(b->d_out + L.path_off);
-  oa.o_refmax = reinterpret_cast<uint32_t*>(b->d_out + L.ref_max);
-  oa.tail = b->d_out + L.a_bytes;
+  // KM_DELIVER_ZEROCOPY=1: the delivery kernels store straight into the pinned host buffer
+  // (PCIe writes from the CUs, no copy command on the stream); default: device buffer + one DMA
+  static const bool zero_copy = getenv("KM_DELIVER_ZEROCOPY") && atoi(getenv("KM_DELIVER_ZEROCOPY")) != 0;
+  unsigned char* dst = zero_copy ? b->h_out : b->d_out;
+  oa.totals = reinterpret_cast<unsigned long long*>(dst + L.totals);
+  oa.o_status = reinterpret_cast<uint32_t*>(dst + L.status);
+  oa.o_nref = reinterpret_cast<uint32_t*>(dst + L.n_ref);
+  oa.o_probes = reinterpret_cast<uint64_t*>(dst + L.probes);
+  oa.o_node_off = reinterpret_cast<uint64_t*>(dst + L.node_off);
+  oa.o_extra_off = reinterpret_cast<uint64_t*>(dst + L.extra_off);
+  oa.o_path_off = reinterpret_cast<uint32_t*>(dst + L.path_off);
+  oa.o_refmax = reinterpret_cast<uint32_t*>(dst + L.ref_max);
+  oa.tail = dst + L.a_bytes;
   oa.tail_cap = b->out_cap - L.a_bytes;
-  hipLaunchKernelGGL(k_out_scan, dim3((n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS), dim3(OUT_SCAN_THREADS), 0, st, oa);
-  hipLaunchKernelGGL(k_out_pack, dim3(n), dim3(64), 0, st, oa);
+  static const int dbg_deliver = getenv("KM_DEBUG_DELIVER") ? atoi(getenv("KM_DEBUG_DELIVER")) : 0;   // timing ablations only
+  if (!(dbg_deliver & 2)) {
+    hipLaunchKernelGGL(k_out_scan, dim3((n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS), dim3(OUT_SCAN_THREADS), 0, st, oa);
+    hipLaunchKernelGGL(k_out_pack, dim3(n), dim3(64), 0, st, oa);
+  }
   HIPCHK(hipGetLastError());
   if (b->timed) HIPCHK(hipEventRecord(b->ev[5], st));
-  const uint64_t guess = std::min<uint64_t>(oa.tail_cap, b->tail_guess);
-  HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, L.a_bytes + guess, hipMemcpyDeviceToHost, st));
+  uint64_t guess = std::min<uint64_t>(oa.tail_cap, b->tail_guess);
+  if (zero_copy) guess = oa.tail_cap;            // everything is already where it belongs
+  else if (!(dbg_deliver & 1)) {
+    HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, L.a_bytes + guess, hipMemcpyDeviceToHost, st));
+  }
   if (b->timed) HIPCHK(hipEventRecord(b->ev[6], st));
   b->timed_deliver = b->timed;
   HIPCHK(hipEventRecord(b->ev_out, st));
@@ -1181,6 +1191,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   const bool want_graph = (stages & KM_RUN_HIPGRAPH) != 0;
   const bool want_deliver = (stages & KM_RUN_DELIVER) != 0;
   const bool want_lean = (stages & KM_DELIVER_LEAN) != 0;
+  const bool want_timed = (stages & KM_RUN_TIMED) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
   b->deliver_pending = b->result_ready = false;
   b->timed_deliver = false;
@@ -1223,7 +1234,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
 
   bool graph_launched = false;
   // a captured step has no host round trips inside
-  b->timed = true;
+  b->timed = want_timed;
   const bool capturing = want_graph && st != nullptr && (stages & KM_STAGE_WALK);   // the NULL stream cannot be captured
   if (capturing) {
     b->timed = false;
@@ -1231,12 +1242,12 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   }
   if (stages & KM_STAGE_WALK) {
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[0], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[3], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
       launch_seed(b->n_items, st, wa);
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[4], st));
     // unflagged targets are final after k_seed: their pure-chain check runs on the side
     // stream while k_dfs (latency-bound, few waves) walks the flagged ones
     HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
@@ -1249,7 +1260,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipEventRecord(e_join, b->side));
     hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     HIPCHK(hipGetLastError());
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
     HIPCHK(hipStreamWaitEvent(st, e_join, 0));
     hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
     HIPCHK(hipGetLastError());
@@ -1259,10 +1270,10 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   } else if (!b->ran_walk) {
     return fail(KM_E_STATE, "graph stage requested before the walk stage");
   } else {
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[0], st));
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[3], st));
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[4], st));
-    if (!capturing) HIPCHK(hipEventRecord(b->ev[1], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[0], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[4], st));
+    if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
   }
   // the graph kernels also host the duplicate-k-mer check, so they always run
   // (graph_mode 1 = stop after that check)
@@ -1271,7 +1282,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     if (rc != KM_OK) return rc;
   }
   b->ran_graph = true;                      // graph_mode says how far it went
-  if (!capturing) HIPCHK(hipEventRecord(b->ev[2], st));
+  if (b->timed) HIPCHK(hipEventRecord(b->ev[2], st));
   if (capturing) {
     HIPCHK(hipStreamEndCapture(st, &b->graph));
     HIPCHK(hipGraphInstantiate(&b->gexec, b->graph, nullptr, nullptr, 0));
@@ -1519,6 +1530,10 @@ static int finish_result(km_batch* b, bool need_full) {
   const unsigned long long* T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
   for (int attempt = 0;; ++attempt) {
     HIPCHK(hipEventSynchronize(b->ev_out));
+    if (getenv("KM_DEBUG_DELIVER") && atoi(getenv("KM_DEBUG_DELIVER"))) {      // timing ablation: nothing valid arrived
+      b->deliver_pending = false; b->result_ready = true;
+      return KM_OK;
+    }
     if (T[OT_SERIAL] != b->serial) return fail(KM_E_HIP, "delivery buffer out of step");
     const unsigned long long nh = T[OT_NEEDS_HOST];
     if (!nh) break;

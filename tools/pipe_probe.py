@@ -19,7 +19,7 @@ case = synth.make_case(n_targets=T * nset, length=L, k=K, n_keys=n_keys, seed=5,
 db = kmlib.Database.from_records(case["keys"], case["counts"], K).upload(0)
 blob = np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()
 offs = np.arange(T + 1, dtype=np.uint64) * np.uint64(L)
-both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | (kmlib.KM_RUN_TIMED if os.environ.get("PROBE_TIMED") else 0)
 for n_fl in fls:
     batches, streams = [], []
     for q in range(n_fl):
@@ -27,16 +27,21 @@ for n_fl in fls:
         b.set_targets_packed(blob[q * T:(q + 1) * T].reshape(-1), offs)
         batches.append(b)
         streams.append(kmlib.stream_create(0))
-    for flags, name in ((both | kmlib.KM_RUN_DELIVER, "deliver"), (both, "kernels only")):
+    lean = both | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN
+    for flags, name in ((both | kmlib.KM_RUN_DELIVER, "deliver"), (lean, "lean"), (lean | kmlib.KM_RUN_HIPGRAPH, "lean+graph"),
+                        (both, "kernels only"), (both | kmlib.KM_RUN_HIPGRAPH, "kernels+graph")):
         wait = bool(flags & kmlib.KM_RUN_DELIVER)
         for rep in range(2):
             steps = 40
             t0 = time.perf_counter()
+            host = 0.0
             for i in range(steps):
                 q = i % n_fl
                 if wait and i >= n_fl:
                     batches[q].wait_result()
+                h0 = time.perf_counter()
                 batches[q].run(flags, streams[q])
+                host += time.perf_counter() - h0
             for b in batches:
                 if wait:
                     b.wait_result()
@@ -44,8 +49,8 @@ for n_fl in fls:
                     b.timings()
             dt = (time.perf_counter() - t0) / steps * 1e3
         tm = np.array([b.timings() for b in batches])
-        print("inflight %d  %-12s  %.3f ms/step   last-run events per batch (ms): walk %s graph %s outk %s d2h %s"
-              % (n_fl, name, dt, np.round(tm[:, 0], 3), np.round(tm[:, 1], 3), np.round(tm[:, 6], 3),
+        print("inflight %d  %-13s  %.3f ms/step (host time in run(): %.3f ms/step)   last-run events per batch (ms): walk %s graph %s outk %s d2h %s"
+              % (n_fl, name, dt, host / steps * 1e3, np.round(tm[:, 0], 3), np.round(tm[:, 1], 3), np.round(tm[:, 6], 3),
                  np.round(tm[:, 7], 3)), flush=True)
     for b in batches:
         b.close()

@@ -33,7 +33,7 @@ b = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=1
                 max_targets=args.targets, max_total_bases=args.targets * args.length)
 b.set_targets_packed(bases.reshape(-1), offs)
 for _ in range(3):
-    b.run(kmlib.KM_STAGE_WALK)
+    b.run(kmlib.KM_STAGE_WALK | kmlib.KM_RUN_TIMED)
     b.sync()
 st = b.debug_stamps().astype(np.int64)
 os.makedirs("gpurun_out", exist_ok=True)
