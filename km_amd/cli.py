@@ -4,7 +4,8 @@ Same flags, same ``#key:value`` echo, same TSV and ``#Elapsed time`` trailer as
 km/tools/find_mutation.py:17-60 and km/argparser/find_mutation.py:4-58, so the
 output pipes into ``km find_report`` unchanged.  The GPU is selected with the
 environment variable KM_DEVICE (no extra flags: the reference's tests index
-output lines).
+output lines); KM_DEVICES=0,1,.. (or a torchrun launch) runs one
+rank per GPU: targets sharded for ``find_mutation``, samples sharded for ``samples``.
 """
 
 import argparse
@@ -55,18 +56,27 @@ def read_target(path):
     return "".join(chunks).upper()
 
 
-def main_find_mut(args, out=sys.stdout):
-    t0 = time.time()
-    for key, val in vars(args).items():
-        out.write("#" + str(key) + ":" + str(val) + "\n")
-    jf = Jellyfish(args.jellyfish_fn, cutoff=args.ratio, n_cutoff=args.count)
-    out.write(report.HEADER + "\n")
-    targets = []
-    for f in list_target_files(args.target_fn):
-        name = os.path.splitext(os.path.basename(f))[0]
-        targets.append((name, read_target(f)))
-    finder = BatchFinder(jf, args.steps, args.branchs, args.nodes)
-    for rows in finder.rows(targets):              # native reporting (km_report_rows)
+CHUNK = 8192          # targets per GPU batch; rows are flushed after every batch
+
+
+def _verbose_lines(name_seq, raw, t, k, err):
+    """The INFO lines of km/utils/MutationFinder.py:101,126,183-187 that the delivered arrays
+    determine (format "VERBOSE: %(message)s", km/tools/find_mutation.py:20-24).  Node indices
+    follow our canonical order (target k-mers first); the reference's depend on its hash seed."""
+    seq = name_seq[1]
+    n_ref = int(raw["n_ref"][t])
+    n_nodes = n_ref + int(raw["extra_off"][t + 1]) - int(raw["extra_off"][t])
+    err.write("VERBOSE: Ref. set contains %d kmers.\n" % n_ref)
+    err.write("VERBOSE: k-mer graph contains %d nodes.\n" % (n_nodes + 2))
+    err.write("VERBOSE: BigBang=%d, BigCrunch=%d\n" % (n_nodes, n_nodes + 1))
+    err.write("VERBOSE: Start kmer %s %d\n" % (seq[:k], 0))
+    err.write("VERBOSE: End   kmer %s %d\n" % (seq[n_ref - 1:n_ref - 1 + k], n_ref - 1))
+    err.write("VERBOSE: %d path(s) from BigBang to BigCrunch.\n"
+              % (int(raw["path_off"][t + 1]) - int(raw["path_off"][t])))
+
+
+def _print_rows(blocks, out):
+    for rows in blocks:
         if isinstance(rows, NodeLimitExceeded):
             out.flush()
             sys.exit(str(rows))
@@ -74,11 +84,84 @@ def main_find_mut(args, out=sys.stdout):
             raise rows
         for row in rows:
             out.write(row + "\n")
+    out.flush()
+
+
+def main_find_mut(args, out=None, err=None):
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    t0 = time.time()
+    if args.graphical:
+        sys.exit("ERROR: -g/--graphical (matplotlib coverage plots, km/utils/MutationFinder.py:591-611) "
+                 "is not supported by km_amd")
+    from . import dist as kd
+    rank, _local_rank, world = kd.env_world()
+    if world > 1:
+        import torch
+        dev = kd.local_device()
+        torch.cuda.set_device(dev)
+        kd.init("nccl", torch.device("cuda", dev))
+    if rank == 0:
+        for key, val in vars(args).items():
+            out.write("#" + str(key) + ":" + str(val) + "\n")
+    targets = []
+    for f in list_target_files(args.target_fn):
+        name = os.path.splitext(os.path.basename(f))[0]
+        targets.append((name, read_target(f)))
+    params = {"ratio": args.ratio, "count": args.count, "steps": args.steps, "branchs": args.branchs,
+              "nodes": args.nodes}
+    if world > 1:
+        # one process per GPU (torchrun, or KM_DEVICES=0,1,.. which starts the ranks): targets are
+        # sharded, the database records cross the links once, rank 0 prints in target order
+        blocks = kd.find_mutation_sharded(targets, args.jellyfish_fn, params=params)
+        if rank == 0:
+            out.write(report.HEADER + "\n")
+            _print_rows(blocks, out)
+            out.write("#Elapsed time:" + str(time.time() - t0) + "\n")
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    jf = Jellyfish(args.jellyfish_fn, cutoff=args.ratio, n_cutoff=args.count)
+    out.write(report.HEADER + "\n")
+    finder = BatchFinder(jf, args.steps, args.branchs, args.nodes)
+    for lo in range(0, len(targets), CHUNK):
+        part = targets[lo:lo + CHUNK]
+        blocks = finder.rows(part)                 # native reporting (km_report_rows)
+        if args.verbose or args.debug:
+            for t in range(len(part)):
+                _verbose_lines(part[t], finder.last_raw, t, jf.k, err)
+        _print_rows(blocks, out)
     out.write("#Elapsed time:" + str(time.time() - t0) + "\n")
 
 
-def main_min_cov(args, out=sys.stdout):
+def main_samples(args, out=None):
+    """catalog x N samples, sample-sharded over the ranks (km_amd.dist.sample_matrix): one TSV
+    stream per target for `km find_report -t <target.fa> -f table`, replacing the loop of
+    example/run_leucegene.sh:29-35."""
+    out = sys.stdout if out is None else out
+    from . import dist as kd
+    rank, _local_rank, world = kd.env_world()
+    if world > 1:
+        import torch
+        dev = kd.local_device()
+        torch.cuda.set_device(dev)
+        kd.init("nccl", torch.device("cuda", dev))
+    params = {"ratio": args.ratio, "count": args.count, "steps": args.steps, "branchs": args.branchs,
+              "nodes": args.nodes}
+    files = kd.sample_matrix(list(args.jellyfish_fn), list_target_files(args.targets), args.out_dir, params)
+    if rank == 0:
+        for f in files:
+            out.write(f + "\n")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_min_cov(args, out=None):
     """km/tools/min_cov.py:10-25 over the batched probe kernel."""
+    out = sys.stdout if out is None else out
     dbs = list_target_files(args.jellyfish_fn)
     seq = args.target_fn
     if os.path.isfile(seq):
@@ -100,11 +183,27 @@ def main(argv=None):
     mc = sub.add_parser("min_cov")
     mc.add_argument("target_fn")
     mc.add_argument("jellyfish_fn", nargs="*")
+    sm = sub.add_parser("samples", help="catalog x N samples -> one TSV stream per target (find_report -f table)")
+    for flag, dest, default, typ in (("-c", "--count", 5, int), ("-p", "--ratio", 0.05, float),
+                                     ("-s", "--steps", 500, int), ("-b", "--branchs", 10, int),
+                                     ("-n", "--nodes", 10000, int)):
+        sm.add_argument(flag, dest, default=default, type=typ)
+    sm.add_argument("-t", "--targets", nargs="+", required=True, help="target FASTA files or one directory")
+    sm.add_argument("-o", "--out-dir", required=True)
+    sm.add_argument("jellyfish_fn", nargs="+", help="one .jf per sample")
     args = parser.parse_args(argv)
     cmd = args._cmd
     del args._cmd
+    # KM_DEVICES=0,1,..: one rank per listed GPU, started here (before anything touches a GPU)
+    if cmd in ("find_mutation", "samples") and "RANK" not in os.environ:
+        from . import dist as kd
+        devs = kd.devices_from_env()
+        if devs and len(devs) > 1:
+            sys.exit(kd.launch_ranks(len(devs), sys.argv[1:] if argv is None else list(argv)))
     if cmd == "find_mutation":
         main_find_mut(args)
+    elif cmd == "samples":
+        main_samples(args)
     elif cmd == "min_cov":
         main_min_cov(args)
     else:

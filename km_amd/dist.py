@@ -1,22 +1,53 @@
-"""Multi-GPU plumbing: one process per GPU over torch.distributed (backend "nccl"
-is RCCL on ROCm; "gloo" for CPU rehearsals).
+"""Multi-GPU find_mutation: one process per GPU over torch.distributed (backend "nccl" is
+RCCL on ROCm; "gloo" for CPU rehearsals).
 
-The path shards embarrassingly by target: every (target x sample)
-unit is independent.  The only exchange is ONE broadcast of the database —
-the compact record arrays (12 B per k-mer), not the sparse 16 B-per-slot table: every
-rank then builds its own HBM table with the insert kernel, which is far cheaper
-than moving the sparse table over xGMI.  Results return to rank 0 in input order.
-No collective sits on the data path.
+The reference runs the loop of km/tools/find_mutation.py:47-58 serially, and its
+Leucegene-scale use is a shell loop over samples (example/run_leucegene.sh:29-35).  Every
+(target x sample) unit is independent, so there are two shardings:
+
+* :func:`find_mutation_sharded` — ONE database, targets sharded in contiguous blocks
+  (BASELINE config 4).  The database crosses the links once, as its compact RECORDS
+  (12 B per k-mer, one packed buffer), not as the sparse 100 B-per-k-mer table: every rank
+  builds its own HBM table from the received records with the device insert kernels
+  (``kmjf_upload_from_device``, 0.05 s per 100 M k-mers), which is 8x less link traffic than
+  broadcasting the table the north-star sketch names.  Results return to rank 0 in input
+  order.  No collective sits on the data path.
+* :func:`find_mutation_samples` / :func:`sample_matrix` — MANY databases, sample-sharded
+  (BASELINE config 5): rank r loads samples r, r + world, ... with ``kmjf_load`` (file -> HBM
+  directly) and runs the whole catalog against each in one batch; no collective at all, only
+  the final gather of the printed rows.
+
+Both take the compute as a callable so that the orchestration can be rehearsed on CPU with
+gloo (tests/test_dist_cpu.py supplies the oracle there); the DEFAULT callables are the HIP
+path (:func:`hip_analyse`, :func:`hip_run_sample`) and are what the CLI and bench.py use.
 """
 
 import os
+import sys
 
 import numpy as np
+
+DEFAULT_PARAMS = {"ratio": 0.05, "count": 5, "steps": 500, "branchs": 10, "nodes": 10000}
 
 
 def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
         int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def devices_from_env():
+    """KM_DEVICES=0,1,2,3 -> [0, 1, 2, 3] (the GPUs a self-launched run may use), else None."""
+    v = os.environ.get("KM_DEVICES", "").strip()
+    if not v:
+        return None
+    return [int(x) for x in v.split(",") if x.strip() != ""]
+
+
+def local_device():
+    """HIP device ordinal of this rank: KM_DEVICES[LOCAL_RANK] if given, else LOCAL_RANK."""
+    _rank, local_rank, _world = env_world()
+    devs = devices_from_env()
+    return devs[local_rank % len(devs)] if devs else local_rank
 
 
 def init(backend=None, device=None):
@@ -33,6 +64,22 @@ def init(backend=None, device=None):
     return rank, local_rank, world
 
 
+def launch_ranks(n, argv, module="km_amd"):
+    """Start `n` ranks of `python -m <module> <argv>` under torch.distributed.run as a CHILD
+    process (this process must not have touched the GPU) and return its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", module] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def shard_range(n, rank, world):
     """Contiguous block [lo, hi) of `n` units for `rank` (sizes differ by at most 1)."""
     base, extra = divmod(n, world)
@@ -41,9 +88,10 @@ def shard_range(n, rank, world):
 
 
 def broadcast_records(keys, counts, k, canonical, device, src=0):
-    """Rank `src` passes numpy (keys uint64, counts uint32); every rank gets torch
-    tensors (int64 / int32 views) on `device` plus (n, k, canonical).  One broadcast
-    of the record arrays — the database's only trip over the links."""
+    """Rank `src` passes numpy (keys uint64, counts uint32); every rank gets torch tensors
+    (int64 / int32 views of ONE packed buffer) on `device` plus (n, k, canonical).  The records
+    are the database's only trip over the links: one data broadcast of 12 B per k-mer, preceded
+    by a 24-byte size message."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -56,15 +104,18 @@ def broadcast_records(keys, counts, k, canonical, device, src=0):
     if world > 1:
         dist.broadcast(meta, src)
     n, k, canonical = (int(x) for x in meta.tolist())
+    n_words = n + (n + 1) // 2                      # n keys, then n counts two to a 64-bit word
     if rank == src:
-        d_keys = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.uint64).view(np.int64)).to(device)
-        d_cnts = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.uint32).view(np.int32)).to(device)
+        host = np.zeros(n_words, dtype=np.int64)
+        host[:n] = np.ascontiguousarray(keys, dtype=np.uint64).view(np.int64)
+        host[n:].view(np.int32)[:n] = np.ascontiguousarray(counts, dtype=np.uint32).view(np.int32)
+        buf = torch.from_numpy(host).to(device)
     else:
-        d_keys = torch.empty(n, dtype=torch.int64, device=device)
-        d_cnts = torch.empty(n, dtype=torch.int32, device=device)
+        buf = torch.empty(n_words, dtype=torch.int64, device=device)
     if world > 1:
-        dist.broadcast(d_keys, src)
-        dist.broadcast(d_cnts, src)
+        dist.broadcast(buf, src)
+    d_keys = buf[:n]
+    d_cnts = buf[n:].view(torch.int32)[:n]
     return d_keys, d_cnts, n, k, bool(canonical)
 
 
@@ -85,17 +136,74 @@ def gather_in_order(local_items, dst=0):
     return out
 
 
-def find_mutation_sharded(targets, db_path, analyse, load_records=None):
-    """Target-sharded find_mutation.  `targets`: list of (name, seq) known to every
-    rank; rank 0 reads the database (`load_records(db_path) -> keys, counts, k,
-    canonical`), broadcasts it once, every rank calls
-    `analyse(d_keys, d_cnts, n, k, canonical, my_targets) -> list[list[str]]`
-    (rows per target) on its shard; rank 0 returns all rows in target order."""
+# ------------------------------------------------------------------------- the HIP compute
+def host_records(path):
+    """`load_records` default: the native host reader (kmjf_open)."""
+    from . import lib as kmlib
+    db = kmlib.Database.open(path)
+    keys, counts = db.records()
+    info = db.info
+    db.close()
+    return keys, counts, int(info.k), bool(info.canonical)
+
+
+def hip_analyse(db_name, params=None, device=None):
+    """`analyse` default for :func:`find_mutation_sharded`: build this rank's table from the
+    broadcast device records (kmjf_upload_from_device) and run its shard through
+    BatchFinder.rows (km_batch_run + lean delivery + km_report_rows)."""
+    prm = dict(DEFAULT_PARAMS, **(params or {}))
+
+    def analyse(d_keys, d_cnts, n, k, canonical, my_targets):
+        import torch
+        from . import lib as kmlib
+        from .finder import BatchFinder
+        from .jellyfish import Jellyfish
+        dev = local_device() if device is None else device
+        db = kmlib.Database.empty(k, canonical)
+        stream = torch.cuda.current_stream().cuda_stream
+        db.upload_from_device(dev, d_keys.data_ptr(), d_cnts.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        jf = Jellyfish(db_name, cutoff=prm["ratio"], n_cutoff=prm["count"], device=dev, db=db)
+        finder = BatchFinder(jf, prm["steps"], prm["branchs"], prm["nodes"])
+        return finder.rows(list(my_targets)) if my_targets else []
+
+    return analyse
+
+
+def hip_run_sample(targets, params=None, device=None):
+    """`run_sample` default for :func:`find_mutation_samples`: kmjf_load(path) on this rank's
+    GPU, the whole catalog in one batch; returns the rows per target."""
+    prm = dict(DEFAULT_PARAMS, **(params or {}))
+
+    def run_sample(path):
+        from .finder import BatchFinder
+        from .jellyfish import Jellyfish
+        dev = local_device() if device is None else device
+        jf = Jellyfish(path, cutoff=prm["ratio"], n_cutoff=prm["count"], device=dev)
+        rows = BatchFinder(jf, prm["steps"], prm["branchs"], prm["nodes"]).rows(list(targets))
+        jf.db.close()
+        return rows
+
+    return run_sample
+
+
+# ------------------------------------------------------------------------- orchestration
+def find_mutation_sharded(targets, db_path, analyse=None, load_records=None, params=None):
+    """Target-sharded find_mutation.  `targets`: list of (name, seq) known to every rank; rank 0
+    reads the database (`load_records(db_path) -> keys, counts, k, canonical`; default: the
+    native host reader), broadcasts its records once, every rank calls
+    `analyse(d_keys, d_cnts, n, k, canonical, my_targets) -> list (rows per target)` on its shard
+    (default: :func:`hip_analyse`); rank 0 returns all of them in target order, other ranks None."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    device = torch.device("cuda", env_world()[1]) if torch.cuda.is_available() else torch.device("cpu")
+    gpu = torch.cuda.is_available() and (not dist.is_initialized() or dist.get_backend() != "gloo")
+    if gpu:
+        torch.cuda.set_device(local_device())
+    device = torch.device("cuda", local_device()) if gpu else torch.device("cpu")
+    analyse = analyse or hip_analyse(db_path, params)
+    load_records = load_records or host_records
     if rank == 0:
         keys, counts, k, canonical = load_records(db_path)
     else:
@@ -107,14 +215,18 @@ def find_mutation_sharded(targets, db_path, analyse, load_records=None):
     return gather_in_order(rows)
 
 
-def find_mutation_samples(db_paths, run_sample):
+def find_mutation_samples(db_paths, run_sample=None, targets=None, params=None):
     """Sample-sharded runs (BASELINE config 5; the shape of example/run_leucegene.sh:29-35):
     rank r opens and processes db_paths[r], db_paths[r + world], ... entirely on its own GPU
-    (`run_sample(path) -> list[str]`); there is no collective on this path, only the final
-    gather of the printed rows, in sample order, on rank 0."""
+    (`run_sample(path)`; default :func:`hip_run_sample` over `targets`); there is no collective on
+    this path, only the final gather of the results, in sample order, on rank 0."""
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if run_sample is None:
+        if targets is None:
+            raise ValueError("find_mutation_samples needs run_sample or targets")
+        run_sample = hip_run_sample(targets, params)
     mine = [(i, run_sample(p)) for i, p in enumerate(db_paths) if i % world == rank]
     if world == 1:
         return [rows for _, rows in mine]
@@ -124,3 +236,41 @@ def find_mutation_samples(db_paths, run_sample):
         return None
     merged = sorted((item for part in bucket for item in part), key=lambda x: x[0])
     return [rows for _, rows in merged]
+
+
+def sample_matrix(db_paths, target_files, out_dir, params=None, run_sample=None, read_target=None):
+    """The Leucegene-scale driver: catalog x N samples, sample-sharded, written
+    as one TSV stream per target — `out_dir/<target>.tsv` holds, sample after sample, exactly what
+    `km find_mutation <target.fa> <sample.jf>` prints (the `#key:value` echo, the header, the rows;
+    the `#Elapsed time` trailer carries 0) — i.e. the concatenation
+    `km find_report -t <target.fa> -f table` consumes (km/tools/find_report.py:290-327), replacing
+    the shell loop of example/run_leucegene.sh:29-35.  Returns the list of files (rank 0)."""
+    from . import report
+    from .cli import read_target as _read_target
+    prm = dict(DEFAULT_PARAMS, **(params or {}))
+    read_target = read_target or _read_target
+    names = [os.path.splitext(os.path.basename(f))[0] for f in target_files]
+    targets = [(nm, read_target(f)) for nm, f in zip(names, target_files)]
+    per_sample = find_mutation_samples(db_paths, run_sample, targets, prm)
+    if per_sample is None:
+        return None
+    os.makedirs(out_dir, exist_ok=True)
+    files = []
+    for ti, (nm, tf) in enumerate(zip(names, target_files)):
+        path = os.path.join(out_dir, nm + ".tsv")
+        with open(path, "w") as fh:
+            for dbp, rows in zip(db_paths, per_sample):
+                for key, val in (("count", prm["count"]), ("ratio", prm["ratio"]), ("steps", prm["steps"]),
+                                 ("branchs", prm["branchs"]), ("nodes", prm["nodes"]), ("graphical", False),
+                                 ("verbose", False), ("debug", False), ("target_fn", [tf]),
+                                 ("jellyfish_fn", dbp)):
+                    fh.write("#%s:%s\n" % (key, val))
+                fh.write(report.HEADER + "\n")
+                block = rows[ti]
+                if isinstance(block, BaseException):
+                    raise block
+                for row in block:
+                    fh.write(row + "\n")
+                fh.write("#Elapsed time:0\n")
+        files.append(path)
+    return files

@@ -82,6 +82,7 @@ class BatchFinder:
         # `raw` are views into that buffer (no host reorganisation, no copy)
         b.run(_lib.KM_STAGE_WALK | _lib.KM_STAGE_GRAPH | _lib.KM_RUN_DELIVER | _lib.KM_DELIVER_LEAN)
         raw = b.result()
+        self.last_raw = raw                          # views into the batch's pinned buffer (CLI -v)
         self._raise_input_errors(raw, names, seqs)
         out = _lib.report_rows(raw, names, seqs, self.jf.k, self.jf.filename if db_name is None else db_name,
                                packed=packed)

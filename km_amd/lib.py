@@ -75,6 +75,30 @@ class ReportIn(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same
+    SONAME as /opt/rocm's): whichever is loaded first serves both libkmgpu.so and torch, and torch
+    finds no GPU when it is the system one.  If torch is installed but not imported yet (a later
+    `import torch` — km_amd.dist, bench.py — must keep working), load ITS runtime first; without
+    torch, or with KM_HIP_RUNTIME=system, libkmgpu.so uses the ROCm installation's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("KM_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libkmgpu.so (built in-tree by ``__graft_entry__.build()``)."""
     global _lib
@@ -83,6 +107,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("km_amd: %s is missing — run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, cp = C.c_void_p, C.c_char_p
     u32, u64, i32, i64, dbl = C.c_uint32, C.c_uint64, C.c_int, C.c_int64, C.c_double

@@ -124,6 +124,15 @@ elif job["kind"] == "children":
     for s in job["kmers"]:
         res.append([s, jf.query(s), jf.get_child(s, forward=True)])
     out = {"children": res}
+elif job["kind"] == "report":
+    from km.tools import find_report as fr
+    ns = argparse.Namespace(target=job["target"], infile=io.StringIO("\n".join(job["lines"]) + "\n"),
+                            info=job.get("info", "vs_ref"), min_cov=job.get("min_cov", 1),
+                            exclu=job.get("exclu", ""), format=job.get("format"))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        fr.create_report(ns)
+    out = {"lines": buf.getvalue().splitlines()}
 elif job["kind"] == "min_cov":
     seqs, _ = uc.file_2_seq(job["target"])
     out = {"cov": list(uc.get_cov(job["db"], "".join(seqs)))}
@@ -275,6 +284,25 @@ def main():
         with open(os.path.join(args.out, "fixtures_children.json"), "w") as fh:
             json.dump(gold, fh)
         print("children/min_cov vectors written")
+
+    # ---- 5. sample matrix: every catalog target against the 5 samples, the
+    #         per-target TSV stream `find_report -f table` consumes, and what it prints
+    if on("matrix"):
+        gold = {"samples": ["./data/jf/" + d for d in DBS], "targets": []}
+        for fa in CATALOG:
+            tfa = "./data/catalog/GRCh38/" + fa
+            stream = []
+            for db in DBS:
+                o, st, _ = r.stable({"kind": "tsv", "targets": [tfa], "db": "./data/jf/" + db}, seeds=[0, 1, 2])
+                assert st and o["exit"] is None, (fa, db)
+                stream += o["lines"]
+            table = r.run({"kind": "report", "target": tfa, "lines": stream, "format": "table"}, 0)["lines"]
+            plain = r.run({"kind": "report", "target": tfa, "lines": stream, "format": None}, 0)["lines"]
+            gold["targets"].append({"target": tfa, "stream": stream, "find_report_table": table,
+                                    "find_report": plain})
+            print("matrix", fa, len(stream), "lines ->", len(table), "table lines")
+        with open(os.path.join(args.out, "sample_matrix.json"), "w") as fh:
+            json.dump(gold, fh, indent=1)
 
     # ---- 4. synthetic slices (generator: km_amd/synth.py) -------------------------
     if on("synth"):

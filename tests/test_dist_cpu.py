@@ -57,6 +57,15 @@ per_sample = kd.find_mutation_samples(SAMPLES, run_sample)
 out["opened"] = opened
 if rank == 0:
     out["per_sample"] = per_sample
+
+# the sample-matrix driver (one TSV stream per target) through the same orchestration
+def run_sample_blocks(path):
+    db = ko.KmerDB(path, cutoff=0.05, n_cutoff=5)
+    return [ko.target_rows(ko.analyse_target(seq, name, db), path) for name, seq in targets]
+files = kd.sample_matrix(SAMPLES, ["./data/catalog/GRCh38/" + f for f in cat], %(outdir)r,
+                         run_sample=run_sample_blocks, read_target=ko.read_fasta_concat)
+if rank == 0:
+    out["matrix_files"] = files
 print("RESULT " + json.dumps(out), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -76,7 +85,8 @@ def test_shard_range_covers_everything():
 
 def test_two_rank_gloo_matches_single_process(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "here": HERE})
+    outdir = str(tmp_path / "matrix")
+    script.write_text(WORKER % {"root": ROOT, "here": HERE, "outdir": outdir})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     port = 29500 + (os.getpid() % 2000)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -99,3 +109,9 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     for d, rows in zip(dbs, by_rank[0]["per_sample"]):
         want = [c for c in gold["cases"] if len(c["targets"]) == 9 and c["db"].endswith(d)][0]
         assert rows == want["lines"][11:]
+    # sample matrix: per-target streams equal the reference's concatenated find_mutation outputs
+    mat = json.load(open(os.path.join(HERE, "golden", "sample_matrix.json")))
+    assert len(by_rank[0]["matrix_files"]) == len(mat["targets"]) == 9
+    for f, want in zip(by_rank[0]["matrix_files"], mat["targets"]):
+        got = [l for l in open(f).read().splitlines() if not l.startswith("#Elapsed time")]
+        assert got == want["stream"], f

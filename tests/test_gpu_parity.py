@@ -436,7 +436,7 @@ def test_full_batch_against_c_oracle():
     b.set_targets([km.decode(r) for r in case["targets"]])
     b.run()
     r = b.fetch()
-    co = c_oracle.COracle(case["keys"][:case["n_real"]], case["counts"][:case["n_real"]], 31)
+    co = c_oracle.COracle(case["keys"], case["counts"], 31)      # EVERY key: a pad 31-mer can neighbour a walk
     noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
     n_multi = 0
     for t in range(3000):
@@ -697,3 +697,96 @@ def test_replay_after_large_tier_and_pool_growth(monkeypatch):
     cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
                     records={"k": 31, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
     _compare_with_oracle(jf, cpu, [(n, s_) for n, s_ in zip(case["names"][:60], seqs[:60])])
+
+
+# ------------------------------------------------------------------ multi-GPU entry points
+def test_dist_entry_points_world_size_1(tmp_path):
+    """km_amd.dist.find_mutation_sharded (records -> device -> kmjf_upload_from_device ->
+    BatchFinder.rows) and km_amd.dist.sample_matrix (kmjf_load per sample, one batch per
+    catalog) with their DEFAULT (HIP) callables, at world size 1, against the golden TSVs."""
+    from km_amd import dist as kd
+    gold = _load("fixtures_tsv.json")["cases"]
+    cat = sorted(os.listdir("./data/catalog/GRCh38"))
+    files = ["./data/catalog/GRCh38/" + f for f in cat]
+    targets = [(os.path.splitext(f)[0], ko.read_fasta_concat("./data/catalog/GRCh38/" + f)) for f in cat]
+    for db in DBS[:3]:
+        case = [c for c in gold if len(c["targets"]) == 9 and c["db"].endswith(db)][0]
+        blocks = kd.find_mutation_sharded(targets, "./data/jf/" + db)
+        assert [r for blk in blocks for r in blk] == case["lines"][11:]
+    mat = _load("sample_matrix.json")
+    out = kd.sample_matrix(mat["samples"], files, str(tmp_path / "matrix"))
+    assert len(out) == 9
+    for f, want in zip(out, mat["targets"]):
+        got = [l for l in open(f).read().splitlines() if not l.startswith("#Elapsed time")]
+        assert got == want["stream"], f
+
+
+def test_cli_verbose_and_graphical(capsys):
+    import argparse
+    from km_amd import cli
+    p = argparse.ArgumentParser()
+    cli.add_find_mutation_args(p)
+    case = _load("fixtures_tsv.json")["cases"][0]
+    args = p.parse_args(["-v"] + case["targets"] + [case["db"]])
+    cli.main_find_mut(args)
+    cap = capsys.readouterr()
+    lines = case["lines"][:]
+    lines[6] = "#verbose:True"
+    assert cap.out.splitlines()[:-1] == lines
+    assert "VERBOSE: Ref. set contains 50 kmers." in cap.err and "VERBOSE: k-mer graph contains 82 nodes." in cap.err
+    args = p.parse_args(["-g"] + case["targets"] + [case["db"]])
+    with pytest.raises(SystemExit, match="not supported"):
+        cli.main_find_mut(args)
+
+
+# ------------------------------------------------------------------ headline size
+def test_headline_table_100M_keys_parity():
+    """BASELINE config 4 at FULL size: the 100 M-key table of bench.py (629 M slots, 2^27
+    minimizer buckets, crowded buckets that probe beyond their home pair).  Lookups of 1 M stored
+    and 20 k absent keys, and 600 of the 10 000 targets — nodes, counts, logical probes, paths,
+    min coverages — against the plain-C oracle holding every key."""
+    from oracle import c_oracle
+    T = 10000
+    case = synth.make_case(n_targets=T, length=500, k=31, n_keys=100_000_000, seed=synth.HEADLINE_SEED,
+                           exact_pad=False)
+    keys, counts = case["keys"], case["counts"]
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    info = db.info
+    assert info.n_records == len(keys) and 99_000_000 < len(keys) <= 100_000_000
+    assert info.n_groups <= 2 * info.n_records and info.n_slots >= 2 * info.n_groups
+    assert 2 <= info.max_probe <= 16, info.max_probe
+    assert info.table_bytes < 140 * len(keys)                    # bytes per k-mer (DESIGN.md §3)
+    co = c_oracle.COracle(keys, counts, 31)
+    rng = np.random.default_rng(11)
+    pick = rng.integers(0, len(keys), size=1_000_000)
+    got = db.query(keys[pick])
+    assert (got == counts[pick]).all()
+    assert (db.query(jr.revcomp_np(keys[pick[:200_000]], 31)) == counts[pick[:200_000]]).all()
+    absent = rng.integers(0, 1 << 62, size=20_000, dtype=np.uint64)
+    want = np.array([co.lib.ko_query(co.h, int(x)) for x in absent], dtype=np.uint32)
+    assert (db.query(absent) == want).all()
+    # the walk + path search over the whole batch, a spread of 600 targets checked in full
+    b = kmlib.Batch(db, max_targets=T, max_total_bases=T * 500)
+    blob = np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].reshape(-1)
+    b.set_targets_packed(blob, np.arange(T + 1, dtype=np.uint64) * np.uint64(500))
+    b.run(kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_DELIVER)
+    r = b.fetch()
+    assert (r["status"] == 0).all() and (r["n_ref"] == 470).all()
+    noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
+    n_multi = 0
+    for t in list(range(0, T, 17)) + list(range(5, 200)):
+        want = co.analyse(case["targets"][t])
+        assert want["status"] == 0
+        assert (r["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all(), t
+        assert (r["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all(), t
+        assert int(r["probes"][t]) == want["probes"], t
+        got = [kmlib.expand_path(r, p).tolist() for p in range(poff[t], poff[t + 1])]
+        assert got == want["paths"], t
+        assert r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"], t
+        n_multi += len(got) > 1
+    assert n_multi > 150
+    # size-independent properties over ALL targets: the counts the walk stored are Jellyfish.query
+    # of the same k-mers, every path runs source -> sink over (k-1)-overlapping nodes
+    assert (db.query(r["node_kmer"][::7]) == r["node_count"][::7]).all()
+    first = np.array([kmlib.expand_path(r, int(poff[t]))[0] for t in range(0, T, 50)])
+    assert (first == 0).all()
