@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--no-ingest", dest="ingest", action="store_false",
                     help="skip the .jf ingestion measurement (writes a 1.2 GB file to the temp dir)")
     ap.add_argument("--cache", default="", help="directory to keep the generated workload in")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
+                    "multi-rank flow, records broadcast through host memory)")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
@@ -269,12 +272,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    bdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
         dist.barrier()
     from km_amd import dist as kd
     from km_amd import lib as kmlib
@@ -283,13 +292,14 @@ def main():
     # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------------
     t_up = time.perf_counter()
     d_keys, d_cnts, n_rec, _k, _canon = kd.broadcast_records(
-        case["keys"] if rank == 0 else None, case["counts"] if rank == 0 else None, K, True, dev)
+        case["keys"] if rank == 0 else None, case["counts"] if rank == 0 else None, K, True, bdev)
     if rank == 0:
-        bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(dev)
+        bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(bdev)
     else:
-        bases_all = torch.empty((T * n_fl, args.length), dtype=torch.uint8, device=dev)
+        bases_all = torch.empty((T * n_fl, args.length), dtype=torch.uint8, device=bdev)
     if world > 1:
         dist.broadcast(bases_all, 0)
+    d_keys, d_cnts, bases_all = d_keys.to(dev).contiguous(), d_cnts.to(dev).contiguous(), bases_all.to(dev)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t_up
     t_build = time.perf_counter()
@@ -372,7 +382,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=bdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt

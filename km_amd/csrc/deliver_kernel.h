@@ -28,7 +28,7 @@
 // Paths of one target are sorted by their node-index sequence here (the canonical order of
 // DESIGN.md §2), nodes carry no per-target slack, nothing is reorganised on the host.
 //
-//  k_out_scan  one thread per target: sizes -> offsets local to a 1024-target block + block totals
+//  k_out_scan  one thread per target: sizes -> offsets local to a 256-target block + block totals
 //  k_out_pack  one wave per target: adds the totals of the blocks before its own (and writes the
 //              batch totals), copies counts / extra k-mers, ranks and emits the paths
 #pragma once
@@ -47,7 +47,7 @@ enum {
   OT_WORDS = 32
 };
 
-constexpr uint32_t OUT_SCAN_THREADS = 1024;
+constexpr uint32_t OUT_SCAN_THREADS = 256;
 
 struct OutArgs {
   uint32_t n_targets;

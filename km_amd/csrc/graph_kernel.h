@@ -319,12 +319,19 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   };
 
   // ---- 1. prefix table: (k-1)-mer prefix -> node index per last base -----------------
-  // EMPTY keys and NONE indices are all-ones bytes.  First only the key array is filled:
-  // inserting the prefixes already tells whether the graph is a bare reference chain.
+  // EMPTY keys and NONE indices are all-ones bytes.  LDS tier: keys, node indices and succ / pred
+  // are filled in one go and a thread remembers the table slot of each of its (at most MAXOWN) nodes,
+  // so the index per (prefix, last base) is written at insertion and the duplicate check re-reads
+  // it without probing again.  Global tier: only the key array first (the common bare-chain exit
+  // needs no more), the rest in 1c.
+  constexpr bool FUSED = !BIG;
+  constexpr uint32_t MAXOWN = 8;               // nodes per thread: ncap < 2048 in the LDS tier
   const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  const uint64_t fill_bytes = graph_region_a<idx_t>(ncap, hcap) + ((((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull);
   {
     uint4* q = reinterpret_cast<uint4*>(wsb);
-    for (uint64_t x = tid; x < (uint64_t)hcap / 2; x += NT) q[x] = ones;      // hcap keys, 8 B each
+    const uint64_t n16 = FUSED ? fill_bytes / 16 : (uint64_t)hcap / 2;       // hcap keys, 8 B each
+    for (uint64_t x = tid; x < n16; x += NT) q[x] = ones;
   }
   {
     const uint64_t* srcw = a.packed + a.woff[t];
@@ -337,10 +344,31 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   if (tid < 8) scal[tid] = 0;
   __syncthreads();
   uint32_t shared_prefix = 0;            // some other node has the same (k-1)-mer prefix
-  for (uint32_t j = tid; j < m; j += NT) {
-    bool wn;
-    const int s = set_insert_lane(pkeys, hcap, nk(j) >> 2, &wn);
-    if (s < 0 || !wn) shared_prefix = 1;
+  uint32_t own_slot[MAXOWN];             // FUSED: 4 * slot + last base of this thread's nodes
+  if constexpr (FUSED) {
+    if (m > MAXOWN * NT) {                 // cannot happen with the LDS tier's geometry
+      if (tid == 0) { a.g_status[t] = T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+      return;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < MAXOWN; ++q) {
+      const uint32_t j = tid + q * NT;
+      own_slot[q] = 0;
+      if (j < m) {
+        bool wn;
+        const uint64_t X = nk(j);
+        const int s = set_insert_lane(pkeys, hcap, X >> 2, &wn);
+        if (s < 0 || !wn) shared_prefix = 1;
+        own_slot[q] = 4u * (uint32_t)(s < 0 ? 0 : s) + (uint32_t)(X & 3);
+        pidx[own_slot[q]] = (idx_t)j;      // a k-mer present twice: the later store wins
+      }
+    }
+  } else {
+    for (uint32_t j = tid; j < m; j += NT) {
+      bool wn;
+      const int s = set_insert_lane(pkeys, hcap, nk(j) >> 2, &wn);
+      if (s < 0 || !wn) shared_prefix = 1;
+    }
   }
   __syncthreads();
 
@@ -394,13 +422,25 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   }
 
   // ---- 1c. general case: node index per (prefix, last base); succ / pred start empty ----
-  {
-    const uint64_t fill_bytes = graph_region_a<idx_t>(ncap, hcap) + ((((uint64_t)ncap * 8 * sizeof(idx_t)) + 15) & ~15ull);
-    uint4* q = reinterpret_cast<uint4*>(wsb);
-    for (uint64_t x = (uint64_t)hcap / 2 + tid; x < fill_bytes / 16; x += NT) q[x] = ones;
-  }
-  __syncthreads();
-  {
+  if constexpr (FUSED) {
+    // a k-mer present twice (km/utils/common.py:55-59) shares one table entry: one of the
+    // two nodes does not find its own index there
+    uint32_t dup = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < MAXOWN; ++q) {
+      const uint32_t j = tid + q * NT;
+      if (j < m && pidx[own_slot[q]] != (idx_t)j) dup = 1;
+    }
+    if (__syncthreads_or((int)dup)) {
+      if (tid == 0) { a.status[t] = T_REPEAT; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+      return;
+    }
+  } else {
+    {
+      uint4* q = reinterpret_cast<uint4*>(wsb);
+      for (uint64_t x = (uint64_t)hcap / 2 + tid; x < fill_bytes / 16; x += NT) q[x] = ones;
+    }
+    __syncthreads();
     uint32_t dup = 0;
     for (uint32_t j = tid; j < m; j += NT) {
       const uint64_t X = nk(j);
@@ -813,41 +853,52 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     return total;
   };
 
-  if (wave != 0) return;                 // emission is wave-uniform work for one wave
-  // pass 1: count runs per path
-  uint32_t total_runs = 0;
-  for (uint32_t p = 0; p < n_cand; ++p)
-    total_runs += walk_path(cand[2 * p], cand[2 * p + 1], [](uint32_t, uint32_t, uint32_t) {});
-  unsigned long long run_base = 0, path_base = 0;
-  unsigned long long over = 0;
-  if (lane == 0) {
-    path_base = atomicAdd(&ctr[0], (unsigned long long)n_cand);
-    run_base = atomicAdd(&ctr[1], (unsigned long long)total_runs);
-    if (path_base + n_cand > pg_paths || run_base + total_runs > pg_runs) {
+  // Emission is wave-uniform work: the candidates are dealt round-robin to the four waves.
+  // pass 1: runs per path
+  uint32_t* cnt_runs = reinterpret_cast<uint32_t*>(frontier);      // [n_cand], the frontiers are dead by now
+  for (uint32_t p = wave; p < n_cand; p += NT / 64) {
+    const uint32_t nr = walk_path(cand[2 * p], cand[2 * p + 1], [](uint32_t, uint32_t, uint32_t) {});
+    if (lane == 0) cnt_runs[p] = nr;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (uint32_t p = 0; p < n_cand; ++p) { const uint32_t c = cnt_runs[p]; cnt_runs[p] = total; total += c; }
+    unsigned long long path_base = atomicAdd(&ctr[0], (unsigned long long)n_cand);
+    unsigned long long run_base = atomicAdd(&ctr[1], (unsigned long long)total);
+    uint32_t over = 0;
+    if (path_base + n_cand > pg_paths || run_base + total > pg_runs) {
       atomicExch(ovf, 1ull);
       over = 1;
     }
     path_base += (uint64_t)pg * pg_paths;
     run_base += (uint64_t)pg * pg_runs;
+    scal[2] = (uint32_t)path_base; scal[3] = (uint32_t)(path_base >> 32);
+    scal[4] = (uint32_t)run_base; scal[5] = (uint32_t)(run_base >> 32);
+    scal[6] = over; scal[7] = total;
   }
-  path_base = __shfl(path_base, 0);
-  run_base = __shfl(run_base, 0);
-  over = __shfl(over, 0);
-  if (over) {        // pools exhausted: host enlarges them and reruns the stage
-    if (lane == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+  __syncthreads();
+  const uint64_t path_base = ((uint64_t)scal[3] << 32) | scal[2];
+  const uint64_t run_base = ((uint64_t)scal[5] << 32) | scal[4];
+  if (scal[6]) {      // pools exhausted: host enlarges them and reruns the stage
+    if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
   }
   // pass 2: write runs, lengths and min coverage
-  uint64_t rcur = run_base;
-  for (uint32_t p = 0; p < n_cand; ++p) {
+  for (uint32_t p = wave; p < n_cand; p += NT / 64) {
+    const uint64_t rcur = run_base + cnt_runs[p];
     uint32_t plen = 0, mincov = 0xFFFFFFFFu;
     const uint32_t nr = walk_path(cand[2 * p], cand[2 * p + 1],
                                   [&](uint32_t start, uint32_t len, uint32_t idx) {
       if (lane == 0) { a.r_start[rcur + idx] = start; a.r_len[rcur + idx] = len; }
       plen += len;
-      for (uint32_t q = lane; q < len; q += 64) {
-        const uint32_t c = ncnt[start + q];
-        mincov = c < mincov ? c : mincov;
+      for (uint32_t q = lane; q < len; q += 256) {      // four independent loads per lane
+        uint32_t c0 = ncnt[start + q], c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
+        if (q + 64 < len) c1 = ncnt[start + q + 64];
+        if (q + 128 < len) c2 = ncnt[start + q + 128];
+        if (q + 192 < len) c3 = ncnt[start + q + 192];
+        c0 = c0 < c1 ? c0 : c1; c2 = c2 < c3 ? c2 : c3; c0 = c0 < c2 ? c0 : c2;
+        mincov = c0 < mincov ? c0 : mincov;
       }
     });
     for (int o = 32; o > 0; o >>= 1) {
@@ -862,13 +913,12 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
       a.p_len[pi] = plen;
       a.p_mincov[pi] = mincov;
     }
-    rcur += nr;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     a.g_status[t] = T_OK;
     a.t_npaths[t] = n_cand;
     a.t_pathbase[t] = (uint32_t)path_base;
-    a.t_nruns[t] = total_runs;
+    a.t_nruns[t] = scal[7];
   }
 }
 
