@@ -16,7 +16,7 @@ for path in sorted(glob.glob(root + "/pmc*/**/*counter_collection.csv", recursiv
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for kname, ctrs in agg.items():
-    if not any(x in kname for x in ("k_seed", "k_dfs", "k_graph", "k_pack")):
+    if not any(x in kname for x in ("k_seed", "k_dfs", "k_graph", "k_pack", "k_out")):
         continue
     out[kname] = {c: sum(v) / len(v) for c, v in ctrs.items()}
     out[kname]["dispatches"] = len(next(iter(ctrs.values())))
@@ -33,5 +33,19 @@ if ks and "TCC_EA0_RDREQ_sum" in ks:
     res["k_seed_hbm_bytes_per_launch"] = rd + wr
     res["note"] = ("reads = RDREQ_128B*128 + RDREQ_64B*64 + RDREQ_32B*32 (FETCH_SIZE counts every "
                    "request as 64 B on gfx950 and under-reports by 2x here); writes = WRITE_SIZE KiB")
+
+
+def hbm_bytes(c):
+    r128 = c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+    r32 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    r64 = c.get("TCC_EA0_RDREQ_sum", 0.0) - r128 - r32
+    return r128 * 128 + r64 * 64 + r32 * 32 + c.get("WRITE_SIZE", 0.0) * 1024
+
+
+# the walk stage = k_pack + k_seed + k_dfs (one launch each per step)
+walk = [v for k_, v in out.items() if k_.startswith(("k_pack", "k_seed", "k_dfs")) and "TCC_EA0_RDREQ_sum" in v]
+if walk:
+    res["walk_stage_hbm_bytes_per_step"] = sum(hbm_bytes(v) for v in walk)
+    res["per_kernel_hbm_bytes"] = {k_: hbm_bytes(v) for k_, v in out.items() if "TCC_EA0_RDREQ_sum" in v}
 json.dump(res, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_avg_per_dispatch"}))
