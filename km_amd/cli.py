@@ -166,13 +166,11 @@ def main_min_cov(args, out=None):
     seq = args.target_fn
     if os.path.isfile(seq):
         seq = read_target(seq)
+    from . import common
     out.write("DB\tcount\tlength\tmin\tmax\tmean\tkmer_nb\tkmer_nb_0\n")
     for db in dbs:
-        jf = Jellyfish(db)
-        c = jf.query_seq(seq).astype("int64")
-        mean = float(c.sum()) / len(c) if len(c) else 0
-        out.write("%s\t%d\t%d\t%d\t%d\t%.2f\t%d\t%d\n" % (db, c.sum(), len(seq), c.min(), c.max(),
-                                                          mean, len(c), int((c == 0).sum())))
+        res = common.get_cov(db, seq)
+        out.write("%s\t%d\t%d\t%d\t%d\t%.2f\t%d\t%d\n" % ((db,) + tuple(res)))
 
 
 def main(argv=None):

@@ -179,7 +179,10 @@ __host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint6
   key->bucket = (uint32_t)(((uint64_t)mm_bucket(c) * t.n_buckets) >> 32);
   // walking forward along a strand moves the minimizer one base to the left: u falls, cls rises
   const uint32_t cls = s * (uint32_t)t.w + ((uint32_t)t.w - 1u - u);
-  const uint32_t h = (uint32_t)key->tag * 0x9E3779B1u;
+  // every bit of the tag takes part: (k-1)-mers that differ only in their first bases (left
+  // siblings, junction k-mers of one variant, error variants of a super-k-mer) share their low
+  // 32 bits, and would share their home pair in every table size
+  const uint32_t h = ((uint32_t)key->tag * 0x9E3779B1u) ^ ((uint32_t)(key->tag >> 32) * 0x85EBCA6Bu);
   key->frac = ((cls << 8) | (h >> 24)) * t.inv32;
   key->cls = cls;
   key->hsub = h;
@@ -280,6 +283,21 @@ __device__ inline uint64_t home_slot(const TableView& t, const Key& key, uint64_
   // small bucket: floor(frac / 2^32 * S), order preserving
   return (uint64_t)(__umulhi(key.frac, (uint32_t)S) & ~1u);
 }
+// Two-choice probing: a key whose home pair is taken moves to a SECOND pair of its bucket, chosen
+// by an independent hash, and only from there on probes linearly (insert and lookup follow the
+// same sequence).  Only buckets that have used up their doublings ever place a key outside its
+// home pair — crowded ones (an odd multiple of NC slots: plain hashing over all pairs) and small
+// ones whose keys share class and leading hash bits; four slots then hold almost every such key,
+// where linear probing from the home pair needed distances of 8-12.
+__device__ inline bool bucket_is_crowded(const TableView& t, uint64_t S) { return ((S >> t.cshift) & 1ull) != 0; }
+__device__ inline uint64_t second_pair(uint64_t tag, uint64_t S, uint64_t home) {
+  uint32_t h = ((uint32_t)(tag >> 32) * 0xC2B2AE35u) ^ ((uint32_t)tag * 0x27D4EB2Fu);
+  h ^= h >> 15;
+  const uint32_t np = (uint32_t)(S >> 1);                  // pairs (>= 2); never the home pair again
+  uint32_t p = (uint32_t)(home >> 1) + 1u + __umulhi(h * 0x165667B1u, np - 1u);
+  if (p >= np) p -= np;
+  return (uint64_t)p << 1;
+}
 // slots of a bucket from its two directory words
 __device__ inline uint64_t bucket_slots(uint32_t lo, uint32_t hi) { return 2ull * (hi - lo); }
 
@@ -302,7 +320,7 @@ __device__ inline uint4 bucket_resolve2(const TableView& t, const Key& key, cons
   const uint64_t t1 = ((uint64_t)a1.y << 32) | a1.x;
   if (t1 == key.tag) return slot_counts(a1);
   if (t1 == EMPTY) return make_uint4(0, 0, 0, 0);
-  idx += 2;
+  idx = S >= 4 ? second_pair(key.tag, S, idx) : idx + 2;
   for (uint32_t step = 2; step < t.max_probe && step < S; ++step) {
     if (idx >= S) idx = 0;
     const uint4 a = *reinterpret_cast<const uint4*>(base + idx);

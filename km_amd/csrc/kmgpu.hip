@@ -287,7 +287,8 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   }
   hipLaunchKernelGGL(k_dir_capacity, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
                      (uint64_t)n_buckets, unit, tv.cshift);
-  const int MAX_ROUNDS = 4;             // CAP_MAX_GEN doublings + 1, then one final round just in case
+  const int MAX_ROUNDS = 5;             // CAP_MAX_GEN dry rounds, up to two more doublings found by the real
+                                        // insert, then one final round that places every key wherever it fits
   unsigned long long meta[6] = {0, 0, 0, 0, 0, 0};
   uint64_t n_slots = 0;
   uint32_t max_probe = 2;

@@ -88,7 +88,9 @@ __device__ inline uint64_t shape_capacity(uint64_t cap, uint64_t NC) {
 constexpr uint32_t CAP_GROW = 0x80000000u;
 constexpr uint32_t CAP_GEN_SHIFT = 29;
 constexpr uint32_t CAP_SIZE = (1u << CAP_GEN_SHIFT) - 1;
-constexpr uint32_t CAP_MAX_GEN = 2;          // doublings per bucket (load 1/2 -> 1/8), then it probes
+constexpr uint32_t CAP_MAX_GEN = 2;          // doublings under the home-pair rule (load 1/2 -> 1/8)
+constexpr uint32_t CAP_HARD_GEN = 3;         // one more for a bucket in which a key fits neither of its
+                                             // two pairs (device_common.h: second_pair); then it probes on
 __device__ inline uint32_t cap_gen(uint32_t c) { return (c >> CAP_GEN_SHIFT) & 3u; }
 
 // Entry count -> initial capacity, in place.
@@ -98,7 +100,7 @@ __global__ void k_dir_capacity(uint32_t* caps, uint64_t n, uint32_t unit, uint32
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t pairs = shape_capacity((uint64_t)caps[i] * unit, NC) >> 1;
     // a bucket too large for the size field starts saturated (it could not double anyway)
-    caps[i] = pairs > CAP_SIZE / 8 ? (uint32_t)(pairs > CAP_SIZE ? CAP_SIZE : pairs) | (CAP_MAX_GEN << CAP_GEN_SHIFT)
+    caps[i] = pairs > CAP_SIZE / 8 ? (uint32_t)(pairs > CAP_SIZE ? CAP_SIZE : pairs) | (CAP_HARD_GEN << CAP_GEN_SHIFT)
                                    : (uint32_t)pairs;
   }
 }
@@ -111,10 +113,12 @@ __global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift) {
     const uint32_t c = caps[i];
     if (!(c & CAP_GROW)) continue;
     const uint32_t gen = cap_gen(c);
-    uint64_t slots = shape_capacity(4ull * (c & CAP_SIZE), NC);
+    // doubling; the extra step of a bucket in which a key fitted neither of its two pairs
+    // (a few hundred buckets in 10^8) quadruples it, so that the rebuild settles it for good
+    uint64_t slots = shape_capacity((gen >= CAP_MAX_GEN ? 8ull : 4ull) * (c & CAP_SIZE), NC);
     // the last doubling of a class-mode bucket turns it into a plain hash table over all its
     // pairs (an odd multiple of NC, see home_slot): its classes are too unevenly filled
-    if (gen + 1 == CAP_MAX_GEN && slots >= 2 * NC) slots += NC;
+    if (gen + 1 >= CAP_MAX_GEN && slots >= 2 * NC) slots += NC;
     caps[i] = (uint32_t)(slots >> 1) | ((gen + 1) << CAP_GEN_SHIFT);
   }
 }
@@ -287,10 +291,15 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
       const uint64_t S = bucket_slots(lo, hi);
       Slot* base = slots + 2ull * lo;
       uint64_t idx = home_slot(t, g, S);
-      const bool may_grow = !final && cap_gen(caps[g.bucket]) < CAP_MAX_GEN;
+      const uint64_t home = idx;
+      const uint32_t gen = cap_gen(caps[g.bucket]);
+      const bool may_grow = !final && gen < CAP_MAX_GEN;
+      const bool may_grow2 = !final && gen < CAP_HARD_GEN;
       bool done = false;
       for (uint64_t step = 0; step < S; ++step) {
         if (step == 2 && may_grow) break;               // the pair is taken: grow this bucket
+        if (step == 2 && S >= 4) idx = second_pair(g.tag, S, home);             // two-choice (device_common.h)
+        if (step == 4 && may_grow2) break;              // neither pair has room: one more doubling
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&base[idx].tag),
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
         claimed += old == EMPTY;
@@ -303,7 +312,7 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
         if (++idx == S) idx = 0;
       }
       if (!done) {
-        if (may_grow) {
+        if (may_grow || may_grow2) {
           if (!(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW)) atomicAdd(&meta[2], 1ull);
         } else {
           atomicExch(reinterpret_cast<unsigned int*>(&meta[1]), 1u);

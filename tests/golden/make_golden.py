@@ -301,6 +301,15 @@ def main():
             gold["targets"].append({"target": tfa, "stream": stream, "find_report_table": table,
                                     "find_report": plain})
             print("matrix", fa, len(stream), "lines ->", len(table), "table lines")
+        # find_report -e <exclusion db>: Exclu_min_cov = common.get_cov(exclu, variant sequence)[2]
+        gold["exclu"] = []
+        for fa, excl in (("FLT3-ITD_exons_13-15.fa", "03H112_IandI.jf"), ("NPM1_4ins_exons_10-11utr.fa", "03H116_ITD.jf"),
+                         ("DNMT3A_R882_exon_23.fa", "02H033_DNMT3A_sub.jf")):
+            tfa = "./data/catalog/GRCh38/" + fa
+            stream = [t for t in gold["targets"] if t["target"] == tfa][0]["stream"]
+            rep = r.run({"kind": "report", "target": tfa, "lines": stream, "format": None,
+                         "exclu": "./data/jf/" + excl}, 0)["lines"]
+            gold["exclu"].append({"target": tfa, "exclu": "./data/jf/" + excl, "find_report": rep})
         with open(os.path.join(args.out, "sample_matrix.json"), "w") as fh:
             json.dump(gold, fh, indent=1)
 

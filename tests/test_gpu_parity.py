@@ -87,7 +87,10 @@ def test_direct_ingestion_matches_host_reader(tmp_path, monkeypatch):
         direct = kmlib.Database.load("./data/jf/" + name, 0)
         hosted = kmlib.Database.open("./data/jf/" + name).upload(0)
         a, b = direct.info, hosted.info
-        assert (a.k, a.canonical, a.n_records, a.n_groups, a.n_slots) == (b.k, b.canonical, b.n_records, b.n_groups, b.n_slots)
+        assert (a.k, a.canonical, a.n_records, a.n_groups) == (b.k, b.canonical, b.n_records, b.n_groups)
+        # which of the few two-choice failures trigger an extra doubling depends on the insertion
+        # order of the parallel build: the slot count may differ by a handful of buckets
+        assert abs(int(a.n_slots) - int(b.n_slots)) <= 0.1 * a.n_slots
         assert (direct.query(d["keys"]) == d["counts"]).all()
         keys, counts = direct.records()
         assert len(keys) == 0 and len(counts) == 0            # no host copy is kept
@@ -193,7 +196,7 @@ def test_table_build_bounds_memory_and_probe_length():
     for name in DBS[:2]:
         jf = Jellyfish("./data/jf/" + name)
         info = jf.db.info
-        assert 2 <= info.max_probe <= 64
+        assert 2 <= info.max_probe <= 4, info.max_probe      # was 12 before the two-choice pairs
         assert info.n_groups <= 2 * info.n_records
         assert 2 * info.n_groups <= info.n_slots <= 40 * info.n_groups
     case = synth.make_case(n_targets=50, length=300, n_keys=200_000, seed=9)
@@ -754,7 +757,7 @@ def test_headline_table_100M_keys_parity():
     info = db.info
     assert info.n_records == len(keys) and 99_000_000 < len(keys) <= 100_000_000
     assert info.n_groups <= 2 * info.n_records and info.n_slots >= 2 * info.n_groups
-    assert 2 <= info.max_probe <= 16, info.max_probe
+    assert 2 <= info.max_probe <= 4, info.max_probe              # two-choice pairs in crowded buckets
     assert info.table_bytes < 140 * len(keys)                    # bytes per k-mer
     co = c_oracle.COracle(keys, counts, 31)
     rng = np.random.default_rng(11)
@@ -790,3 +793,76 @@ def test_headline_table_100M_keys_parity():
     assert (db.query(r["node_kmer"][::7]) == r["node_count"][::7]).all()
     first = np.array([kmlib.expand_path(r, int(poff[t]))[0] for t in range(0, T, 50)])
     assert (first == 0).all()
+
+
+def test_find_report_exclusion_coverage():
+    """`km find_report -e <db>` calls common.get_cov(db, variant sequence) per row and prints its
+    min (km/tools/find_report.py:137-139, km/utils/common.py:73-92).  km_amd.common.get_cov /
+    get_cov_many (one kmjf_query_batch launch) against the Exclu_min_cov column the reference's
+    find_report printed (tests/golden/sample_matrix.json)."""
+    from km_amd import common
+    mat = _load("sample_matrix.json")
+    for case in mat["exclu"]:
+        stream = [t for t in mat["targets"] if t["target"] == case["target"]][0]["stream"]
+        seqs = []
+        for line in stream:
+            tok = line.split("\t")
+            if line.startswith("#") or "vs_ref" not in line or tok[0] == "Database" or len(tok) <= 1:
+                continue
+            if int(tok[6]) < 1:                      # find_report's -m 1 filter
+                continue
+            seqs.append(tok[8])
+        want = [l.split("\t")[10] for l in case["find_report"][1:]]
+        assert len(seqs) == len(want) and len(seqs) >= 2
+        many = common.get_cov_many(case["exclu"], seqs)
+        assert [str(r[2]) for r in many] == want
+        for s_, r in zip(seqs[:3], many[:3]):
+            assert common.get_cov(case["exclu"], s_) == r
+    # the known answers of km/tests/test_main.py:625-652 through the same helper
+    seq = ko.read_fasta_concat("./data/catalog/GRCh38/FLT3-ITD_exons_13-15.fa")
+    r = common.get_cov("./data/jf/03H112_IandI.jf", seq)
+    assert r[:4] == (275596, 345, 618, 1368) and "%.2f" % r[4] == "874.91" and r[5:] == (315, 0)
+    common.close_all()
+
+
+def test_table_capacity_limit_and_beyond_1G_slots():
+    """The stated limit of one table — fewer than 2^31 entries (a canonical record is entered under
+    both orientations: 2^30 canonical k-mers), the directory being 32-bit — is refused with
+    KM_E_CAPACITY before anything is allocated; below it, a table of more than 2^30 slots (330 M
+    random non-canonical 31-mers generated on the device) is built and answers exactly."""
+    import torch
+    dev = torch.device("cuda", 0)
+    tiny_k = torch.zeros(4, dtype=torch.int64, device=dev)
+    tiny_c = torch.ones(4, dtype=torch.int32, device=dev)
+    db = kmlib.Database.empty(31, True)
+    with pytest.raises(kmlib.KmError) as ei:
+        db.upload_from_device(0, tiny_k.data_ptr(), tiny_c.data_ptr(), 1 << 30)
+    assert ei.value.code == 8                                   # KM_E_CAPACITY
+    db.close()
+    n = 330_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    keys = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g)
+    keys = torch.unique(keys)                                   # sorted, distinct
+    n = int(keys.numel())
+    counts = ((keys * 2654435761) >> 7).to(torch.int32).remainder(60000) + 1     # a count derived from the key
+    db = kmlib.Database.empty(31, False)
+    db.upload_from_device(0, keys.data_ptr(), counts.data_ptr(), n)
+    torch.cuda.synchronize()
+    info = db.info
+    assert info.n_slots > (1 << 30) and info.n_groups <= n and 2 <= info.max_probe <= 16
+    pick = torch.randint(0, n, (2_000_000,), device=dev, generator=g)
+    q, want = keys[pick].contiguous(), counts[pick].contiguous()
+    got = torch.empty(q.numel(), dtype=torch.int32, device=dev)
+    db.query_dev(q.data_ptr(), q.numel(), got.data_ptr())
+    torch.cuda.synchronize()
+    assert bool((got == want).all())
+    absent = torch.randint(0, 1 << 62, (1_000_000,), dtype=torch.int64, device=dev, generator=g)
+    pos = torch.searchsorted(keys, absent).clamp(max=n - 1)
+    present = keys[pos] == absent
+    exp = torch.where(present, counts[pos], torch.zeros_like(counts[pos]))
+    got = torch.empty(absent.numel(), dtype=torch.int32, device=dev)
+    db.query_dev(absent.data_ptr(), absent.numel(), got.data_ptr())
+    torch.cuda.synchronize()
+    assert bool((got == exp).all())
+    db.close()
