@@ -158,9 +158,10 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     for (uint32_t w = tid; w <= nwords; w += NT) words[w] = src[w];
   }
   // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of
-  // the last) distinct?  A set of 32-bit FINGERPRINTS at load <= 1/4 answers it: equal
+  // the last) distinct?  A set of 32-bit FINGERPRINTS at load <= 1/2 answers it: equal
   // (k-1)-mers always meet (same fingerprint, same home); two different ones with the same
-  // fingerprint (2.6e-5 per target) only send the target to k_graph, which decides exactly.
+  // fingerprint (2.6e-5 per target, whatever the load) only send the target to k_graph, which
+  // decides exactly.
   uint32_t* fps = reinterpret_cast<uint32_t*>(smem);
   {
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
