@@ -1078,9 +1078,9 @@ static void fast_geometry(km_batch* b) {
   ga.hcap = round_up(ga.ncap + ga.ncap / 2 + 1, 64);
   ga.words_cap = wa.words_cap;
   b->graph_lds = (uint32_t)graph_ws_bytes<uint16_t>(ga.ncap, ga.hcap, ga.words_cap);
-  ga.hcap_pure = round_up(2 * (nref + 2), 64);                   // 32-bit fingerprints at load <= 1/2 (measured:
-                                                                 // 1/4 97 us, 1/2 69 us, 3/4 95 us — resident waves
-                                                                 // against probe chains)
+  ga.hcap_pure = round_up(2 * (nref + 2), 64);                   // 32-bit fingerprints at load <= 1/2 (pipelined step
+                                                                 // vs load 1/4: -2.5 %; load 3/4: +3 % — resident
+                                                                 // waves against probe chains)
   b->pure_lds = ga.hcap_pure * 4 + ga.words_cap * 8;
   if (b->pure_lds > FAST_LDS_LIMIT) {                            // all -> need_full
     ga.hcap_pure = 64;
