@@ -81,6 +81,9 @@ struct OutArgs {
   unsigned long long* loc;             // [n][4] offsets (nodes, extra, paths, runs) local to the scan block
   uint32_t* cnt;                       // [n][4] the four sizes of each target
   unsigned long long* blk_tot;         // [scan blocks][8] block totals: 4 sizes, probes, fetches, seed probes, needs-host
+  unsigned long long* blk_base;        // [scan blocks][4] sizes of all blocks before this one (written by the block
+                                       // that finishes last); [nblk][8] behind them: the batch totals
+  unsigned int* scan_ticket;           // blocks done so far (reset by the last one)
   unsigned long long* psort;           // [path pool] (source path << 32 | runs) in sorted order
   // delivery buffer
   unsigned long long* totals;
@@ -182,10 +185,47 @@ __global__ __launch_bounds__(OUT_SCAN_THREADS) void k_out_scan(OutArgs a) {
     *L = make_ulonglong4(ex[0], ex[1], ex[2], ex[3]);
     reinterpret_cast<uint4*>(a.cnt)[t] = make_uint4((uint32_t)s[0], (uint32_t)s[1], (uint32_t)s[2], (uint32_t)s[3]);
   }
+  __shared__ unsigned int last_flag;
   if (tid == 0) {
     unsigned long long* B = a.blk_tot + 8ull * blockIdx.x;
     B[0] = tot[0]; B[1] = tot[1]; B[2] = tot[2]; B[3] = tot[3];
     B[4] = stat[0]; B[5] = stat[1]; B[6] = stat[2]; B[7] = stat[3];
+    __threadfence();                                       // totals visible before the ticket
+    last_flag = atomicAdd(a.scan_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_flag || wave != 0) return;
+  // The block that finishes last turns the block totals into exclusive prefixes (one wave, 64
+  // blocks per round) so that k_out_pack finds its base with two loads instead of a reduction.
+  const uint32_t nblk = gridDim.x;
+  unsigned long long carry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+    const uint32_t bq = b0 + lane;
+    unsigned long long v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      v[q] = bq < nblk ? __hip_atomic_load(a.blk_tot + 8ull * bq + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      unsigned long long inc = v[q];
+      if (q == 7) {                                        // needs-host flags: OR
+        for (int o = 1; o < 64; o <<= 1) inc |= __shfl_xor(inc, o);
+        carry[q] |= inc;
+      } else {
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned long long u = __shfl_up(inc, o);
+          if ((int)lane >= o) inc += u;
+        }
+        if (q < 4 && bq < nblk) a.blk_base[4ull * bq + q] = carry[q] + inc - v[q];
+        carry[q] += __shfl(inc, 63);
+      }
+    }
+  }
+  if (lane == 0) {
+    unsigned long long* G = a.blk_base + 4ull * nblk;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) G[q] = carry[q];
+    *a.scan_ticket = 0u;
   }
 }
 
@@ -209,25 +249,17 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
   const uint32_t t = blockIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n = a.n_targets;
-  // ---- global offsets: block totals before this target's scan block + grand totals
+  // ---- global offsets: sizes of the scan blocks before this target's + the batch totals
+  // (prefix sums by the last block of k_out_scan)
   const uint32_t nblk = (n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS, myblk = t / OUT_SCAN_THREADS;
-  unsigned long long pre[4] = {0, 0, 0, 0}, tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
-    const uint32_t bq = b0 + lane;
-    const ulonglong4* B = reinterpret_cast<const ulonglong4*>(a.blk_tot + 8ull * bq);
-    ulonglong4 x = make_ulonglong4(0, 0, 0, 0), y = x;
-    if (bq < nblk) { x = B[0]; y = B[1]; }
-    const bool before = bq < myblk;
-    pre[0] += before ? x.x : 0; pre[1] += before ? x.y : 0; pre[2] += before ? x.z : 0; pre[3] += before ? x.w : 0;
-    tot[0] += x.x; tot[1] += x.y; tot[2] += x.z; tot[3] += x.w;
-    tot[4] += y.x; tot[5] += y.y; tot[6] += y.z; tot[7] |= y.w;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pre[q] += __shfl_xor(pre[q], o);
-#pragma unroll
-    for (int q = 0; q < 7; ++q) tot[q] += __shfl_xor(tot[q], o);
-    tot[7] |= __shfl_xor(tot[7], o);
+  unsigned long long pre[4], tot[8];
+  {
+    const ulonglong4 pb = *reinterpret_cast<const ulonglong4*>(a.blk_base + 4ull * myblk);
+    const ulonglong4* G = reinterpret_cast<const ulonglong4*>(a.blk_base + 4ull * nblk);
+    const ulonglong4 g0 = G[0], g1 = G[1];
+    pre[0] = pb.x; pre[1] = pb.y; pre[2] = pb.z; pre[3] = pb.w;
+    tot[0] = g0.x; tot[1] = g0.y; tot[2] = g0.z; tot[3] = g0.w;
+    tot[4] = g1.x; tot[5] = g1.y; tot[6] = g1.z; tot[7] = g1.w;
   }
   uint64_t o = 0;
   const uint64_t off_count = o;  o = out_align(o + 4 * tot[0]);

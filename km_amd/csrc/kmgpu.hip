@@ -681,7 +681,8 @@ struct km_batch {
   DevBuf<uint64_t> d_p_runbase;
   uint64_t path_pool = 0, run_pool = 0;
   // delivery (deliver_kernel.h): device buffer in its final host layout + its pinned host twin
-  DevBuf<unsigned long long> d_loc, d_blk_tot, d_psort;
+  DevBuf<unsigned long long> d_loc, d_blk_tot, d_blk_base, d_psort;
+  DevBuf<unsigned int> d_scan_ticket;
   DevBuf<uint32_t> d_cnt4;
   unsigned char* d_out = nullptr;
   unsigned char* h_out = nullptr;
@@ -774,6 +775,9 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_loc.alloc(4ull * max_targets));
   A(b->d_cnt4.alloc(4ull * max_targets));
   A(b->d_blk_tot.alloc(8ull * (max_targets / OUT_SCAN_THREADS + 1)));
+  A(b->d_blk_base.alloc(4ull * (max_targets / OUT_SCAN_THREADS + 1) + 8));
+  A(b->d_scan_ticket.alloc(1));
+  if (rc == KM_OK && hipMemset(b->d_scan_ticket.p, 0, 4) != hipSuccess) rc = fail(KM_E_HIP, "hipMemset failed");
   A(b->d_probes.alloc(max_targets));
   A(b->d_fetches.alloc(max_targets));
   const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA;
@@ -832,7 +836,7 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
   b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release(); b->d_t_nruns.release(); b->d_t_refmax.release();
-  b->d_loc.release(); b->d_cnt4.release(); b->d_blk_tot.release(); b->d_psort.release();
+  b->d_loc.release(); b->d_cnt4.release(); b->d_blk_tot.release(); b->d_blk_base.release(); b->d_scan_ticket.release(); b->d_psort.release();
   if (b->side) (void)hipStreamDestroy(b->side);
   if (b->ev_seed_done) (void)hipEventDestroy(b->ev_seed_done);
   if (b->ev_pure_done) (void)hipEventDestroy(b->ev_pure_done);
@@ -1137,6 +1141,7 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.p_runbase = b->d_p_runbase.p; oa.p_nruns = b->d_p_nruns.p; oa.p_len = b->d_p_len.p;
   oa.p_mincov = b->d_p_mincov.p; oa.r_start = b->d_r_start.p; oa.r_len = b->d_r_len.p;
   oa.loc = b->d_loc.p; oa.cnt = b->d_cnt4.p; oa.blk_tot = b->d_blk_tot.p; oa.psort = b->d_psort.p;
+  oa.blk_base = b->d_blk_base.p; oa.scan_ticket = b->d_scan_ticket.p;
   // KM_DELIVER_ZEROCOPY=1: the delivery kernels store straight into the pinned host buffer
   // (PCIe writes from the CUs, no copy command on the stream); default: device buffer + one DMA
   static const bool zero_copy = getenv("KM_DELIVER_ZEROCOPY") && atoi(getenv("KM_DELIVER_ZEROCOPY")) != 0;
