@@ -204,6 +204,29 @@ __host__ __device__ inline Key make_key(const TableView& t, uint64_t P) {
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Kernels instantiated for one k (K = 31: what `jellyfish count -m 31` and every bundled file
+// use) see the geometry of the table view as compile-time constants: shifts, masks and the window
+// loops fold, and a dozen scalar registers stop being live across the kernel.  K = 0: as given.
+template <int K>
+__device__ inline TableView specialized_view(const TableView& v) {
+  TableView t = v;
+  if constexpr (K != 0) {
+    constexpr int M = (K - 1 < 15 ? K - 1 : 15) - (((K - 1 < 15 ? K - 1 : 15) & 1) ? 0 : 1);
+    constexpr int W = K - M;
+    t.k = K;
+    t.m = M;
+    t.w = W;
+    t.kmask = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
+    t.pmask = (1ull << (2 * (K - 1))) - 1;
+    t.mmask = (uint32_t)((1ull << (2 * M)) - 1);
+    t.inv32 = (uint32_t)((1ull << 32) / ((uint64_t)2 * W * 256));
+    uint32_t cs = 1;
+    while ((1u << cs) < 2u * (uint32_t)W) ++cs;
+    t.cshift = cs;
+  }
+  return t;
+}
+
 // k-mer i of a 2-bit packed target (32 bases per word, first base most significant; the
 // packed form carries one extra zero word, so words[w + 1] is always readable)
 __device__ inline uint64_t kmer_from_words(const uint64_t* words, uint32_t i, int k) {

@@ -1103,8 +1103,9 @@ static int launch_graph_fast(km_batch* b, hipStream_t st) {
 }
 
 static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
-  if (wa.stamps) hipLaunchKernelGGL(k_seed<true>, dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);   // KM_SEED_STAMPS diagnostics
-  else hipLaunchKernelGGL(k_seed<false>, dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+  if (wa.stamps) hipLaunchKernelGGL((k_seed<true, 0>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);   // KM_SEED_STAMPS diagnostics
+  else if (wa.tab.k == 31) hipLaunchKernelGGL((k_seed<false, 31>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+  else hipLaunchKernelGGL((k_seed<false, 0>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
 }
 
 // Compaction kernels + ONE asynchronous copy of region A and the expected part of the tail into
@@ -1266,7 +1267,8 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     ga.use_need_full = 1;
     hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, b->side, ga);
     HIPCHK(hipEventRecord(e_join, b->side));
-    hipLaunchKernelGGL(k_dfs<false>, dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
+    if (wa.tab.k == 31) hipLaunchKernelGGL((k_dfs<false, 31>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
+    else hipLaunchKernelGGL((k_dfs<false, 0>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     HIPCHK(hipGetLastError());
     if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
     HIPCHK(hipStreamWaitEvent(st, e_join, 0));
@@ -1385,7 +1387,7 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
     const uint32_t cnt = std::min(per, nb - s);
     a.list = b->d_big_ids.p + s;
     a.n_list_host = cnt;
-    hipLaunchKernelGGL(k_dfs<true>, dim3(cnt), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_dfs<true, 0>), dim3(cnt), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
   }

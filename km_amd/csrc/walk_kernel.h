@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
 //    (one LDS round trip: w/2 ds_read2 + w/2 v_min3);
 //  * the lookup is key -> directory word -> the aligned home pair, three dependent loads with
 //    no loop (device_common.h: the build guarantees the pair).
-template <bool STAMPS>
+template <bool STAMPS, int K>
 __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   static_assert(SEED_BLOCK == 256, "the item record holds 12 words = 256 seeds + k - 1 + 1 bases");
   constexpr uint32_t RAW = SEED_BLOCK + 32;                // selection keys of the item's m-mers
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   uint32_t probes_first = 0;                               // diagnostics: slots read by this lane's lookup
   if constexpr (STAMPS) real0 = __builtin_amdgcn_s_memrealtime();
   KM_SEED_STAMP(0);
-  const TableView tab = a.tab;
+  const TableView tab = specialized_view<K>(a.tab);
   const int k = tab.k;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
 }
 
 // ---------------------------------------------------------------------------- k_dfs
-template <bool BIG>
+template <bool BIG, int K>
 __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t lane = (uint32_t)lane_id();
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   if (blockIdx.x >= n_list) return;
   const uint32_t t = a.list[blockIdx.x];
   if (a.status[t] != T_OK && a.status[t] != T_NEEDS_BIG) return;
-  const TableView tab = a.tab;
+  const TableView tab = specialized_view<K>(a.tab);
   const int k = tab.k;
 
   unsigned char* wsb;
