@@ -125,7 +125,13 @@ __host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap,
 // and the last k-mer's suffix not among them — and if so emit its single path.  Small LDS
 // (prefix keys only), so it runs at full occupancy and overlaps k_dfs on a second stream.
 // Everything else is left to k_graph through need_full[].
+template <int K>
 __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
+  if constexpr (K != 0) {               // instantiated for one k: shifts and masks fold
+    a.k = K;
+    a.kmask = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
+    a.pmask = (1ull << (2 * (K - 1))) - 1;
+  }
   extern __shared__ __align__(16) unsigned char smem[];
   // one wave per target: this pass runs beside k_dfs, it should take few wave slots
   const uint32_t lane = threadIdx.x & 63u, NT = 64;
@@ -232,9 +238,14 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   }
 }
 
-template <bool BIG>
+template <bool BIG, int K>
 __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   GraphArgs a = a0;
+  if constexpr (K != 0) {               // instantiated for one k: shifts and masks fold
+    a.k = K;
+    a.kmask = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
+    a.pmask = (1ull << (2 * (K - 1))) - 1;
+  }
   const bool keep_pure = (a.dbg & 0x80u) != 0;   // ablation: pure pass stays active
   a.dbg &= 0x7Fu;
   using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;

@@ -1092,12 +1092,22 @@ static void fast_geometry(km_batch* b) {
   }
 }
 
+// LDS-tier graph kernels, instantiated for k = 31 where that is the database's k
+static void launch_pure(km_batch* b, hipStream_t st, const GraphArgs& ga) {
+  if (ga.k == 31) hipLaunchKernelGGL((k_graph_pure<31>), dim3(b->n_targets), dim3(64), b->pure_lds, st, ga);
+  else hipLaunchKernelGGL((k_graph_pure<0>), dim3(b->n_targets), dim3(64), b->pure_lds, st, ga);
+}
+static void launch_graph(km_batch* b, hipStream_t st, const GraphArgs& ga) {
+  if (ga.k == 31) hipLaunchKernelGGL((k_graph<false, 31>), dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+  else hipLaunchKernelGGL((k_graph<false, 0>), dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+}
+
 // Graph stage on one stream: pure-chain pass, then the general kernel for the rest.
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
   b->ga.use_need_full = 1;
-  hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, st, b->ga);
-  hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, b->ga);
+  launch_pure(b, st, b->ga);
+  launch_graph(b, st, b->ga);
   HIPCHK(hipGetLastError());
   return KM_OK;
 }
@@ -1265,14 +1275,14 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipEventRecord(e_fork, st));
     HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
     ga.use_need_full = 1;
-    hipLaunchKernelGGL(k_graph_pure, dim3(b->n_targets), dim3(64), b->pure_lds, b->side, ga);
+    launch_pure(b, b->side, ga);
     HIPCHK(hipEventRecord(e_join, b->side));
     if (wa.tab.k == 31) hipLaunchKernelGGL((k_dfs<false, 31>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     else hipLaunchKernelGGL((k_dfs<false, 0>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     HIPCHK(hipGetLastError());
     if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
     HIPCHK(hipStreamWaitEvent(st, e_join, 0));
-    hipLaunchKernelGGL(k_graph<false>, dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+    launch_graph(b, st, ga);
     HIPCHK(hipGetLastError());
     graph_launched = true;
     b->ran_walk = true;
@@ -1413,7 +1423,7 @@ static int run_big_graph(km_batch* b, const std::vector<uint32_t>& ids, hipStrea
   for (uint32_t s = 0; s < nb; s += per) {
     const uint32_t cnt = std::min(per, nb - s);
     g.tids = b->d_big_ids.p + s;
-    hipLaunchKernelGGL(k_graph<true>, dim3(cnt), dim3(GRAPH_THREADS), 0, st, g);
+    hipLaunchKernelGGL((k_graph<true, 0>), dim3(cnt), dim3(GRAPH_THREADS), 0, st, g);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
   }
