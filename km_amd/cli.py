@@ -100,7 +100,7 @@ def main_find_mut(args, out=None, err=None):
         import torch
         dev = kd.local_device()
         torch.cuda.set_device(dev)
-        kd.init("nccl", torch.device("cuda", dev))
+        kd.init(os.environ.get("KM_DIST_BACKEND", "nccl"), torch.device("cuda", dev))
     if rank == 0:
         for key, val in vars(args).items():
             out.write("#" + str(key) + ":" + str(val) + "\n")
@@ -146,7 +146,7 @@ def main_samples(args, out=None):
         import torch
         dev = kd.local_device()
         torch.cuda.set_device(dev)
-        kd.init("nccl", torch.device("cuda", dev))
+        kd.init(os.environ.get("KM_DIST_BACKEND", "nccl"), torch.device("cuda", dev))
     params = {"ratio": args.ratio, "count": args.count, "steps": args.steps, "branchs": args.branchs,
               "nodes": args.nodes}
     files = kd.sample_matrix(list(args.jellyfish_fn), list_target_files(args.targets), args.out_dir, params)

@@ -159,6 +159,10 @@ def hip_analyse(db_name, params=None, device=None):
         from .finder import BatchFinder
         from .jellyfish import Jellyfish
         dev = local_device() if device is None else device
+        torch.cuda.set_device(dev)
+        if not d_keys.is_cuda:             # a gloo rehearsal broadcasts through host memory
+            d_keys, d_cnts = d_keys.to("cuda:%d" % dev), d_cnts.to("cuda:%d" % dev)
+        d_keys, d_cnts = d_keys.contiguous(), d_cnts.contiguous()
         db = kmlib.Database.empty(k, canonical)
         stream = torch.cuda.current_stream().cuda_stream
         db.upload_from_device(dev, d_keys.data_ptr(), d_cnts.data_ptr(), n, stream)

@@ -866,3 +866,32 @@ def test_table_capacity_limit_and_beyond_1G_slots():
     torch.cuda.synchronize()
     assert bool((got == exp).all())
     db.close()
+
+
+def test_cli_two_ranks_target_sharded(tmp_path):
+    """`python -m km_amd find_mutation` with two ranks started by KM_DEVICES (the CLI launches
+    torch.distributed.run itself): targets sharded, records broadcast, every rank's shard through
+    the HIP path, rows gathered on rank 0 — the golden TSV.  On a one-GPU box both ranks share
+    device 0 and the broadcast goes through host memory (gloo); with two GPUs it is RCCL."""
+    import subprocess
+    import sys
+    import torch
+    two = torch.cuda.device_count() >= 2
+    case = [c for c in _load("fixtures_tsv.json")["cases"] if len(c["targets"]) == 9 and c["db"].endswith("03H116_ITD.jf")][0]
+    env = dict(os.environ, KM_DEVICES="0,1" if two else "0,0", KM_DIST_BACKEND="nccl" if two else "gloo",
+               PYTHONPATH=os.path.dirname(HERE))
+    p = subprocess.run([sys.executable, "-m", "km_amd", "find_mutation"] + case["targets"] + [case["db"]],
+                       cwd=HERE, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [l for l in p.stdout.splitlines() if not l.startswith("#Elapsed time") and "peer ranks" not in l]   # gloo chatters on stdout
+    assert out == case["lines"]
+    # sample-sharded driver, two ranks
+    mat = _load("sample_matrix.json")
+    files = [t["target"] for t in mat["targets"]]
+    p = subprocess.run([sys.executable, "-m", "km_amd", "samples", "-t"] + files + ["-o", str(tmp_path / "m")] + mat["samples"],
+                       cwd=HERE, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    for t in mat["targets"]:
+        name = os.path.splitext(os.path.basename(t["target"]))[0]
+        got = [l for l in open(str(tmp_path / "m" / (name + ".tsv"))).read().splitlines() if not l.startswith("#Elapsed time")]
+        assert got == t["stream"], name
