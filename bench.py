@@ -63,16 +63,42 @@ def _cpu_init(case, n_need):
     _CPU["n_keys"] = int(sel.sum())
 
 
-def _cpu_work(span):
+def _cpu_work(span, phases=None):
     from km_amd import kmer as km
     from oracle import km_oracle as ko
     case, db = _CPU["case"], _CPU["db"]
     probes = 0
     t0 = time.perf_counter()
     for i in range(*span):
-        res = ko.analyse_target(km.decode(case["targets"][i]), case["names"][i], db)
+        seq, name = km.decode(case["targets"][i]), case["names"][i]
+        if phases is None:
+            res = ko.analyse_target(seq, name, db)
+        else:                                  # the same calls, timed per phase
+            ta = time.perf_counter()
+            mers = ko.ref_kmers(seq, name, db.k)
+            p0 = db.probes
+            nodes = ko.walk(mers, db)
+            tb = time.perf_counter()
+            kmers, counts = list(nodes.keys()), list(nodes.values())
+            paths = ko.graph_paths(kmers, len(mers))
+            tc = time.perf_counter()
+            res = {"name": name, "k": db.k, "n_ref": len(mers), "kmers": kmers, "counts": counts, "paths": paths,
+                   "probes": db.probes - p0, "min_cov": [min(counts[j] for j in p) for p in paths]}
+            ko.target_rows(res, "synthetic.jf")
+            td = time.perf_counter()
+            phases[0] += tb - ta; phases[1] += tc - tb; phases[2] += td - tc
         probes += res["probes"]
     return probes, time.perf_counter() - t0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def usable_cores():
@@ -108,13 +134,22 @@ def cpu_baseline(case, n_sample):
     per = max(8, n_sample // 4)
     n_all = per * cores
     n_need = min(len(case["targets"]), max(n_sample, n_all))
+    t_load = time.perf_counter()
     _cpu_init(case, n_need)
+    t_load = time.perf_counter() - t_load
     n_sample = min(n_sample, n_need)
     probes, dt = _cpu_work((0, n_sample))
+    ph = [0.0, 0.0, 0.0]
+    n_ph = min(60, n_sample)
+    _cpu_work((0, n_ph), ph)
     out = {"value": n_sample / dt, "unit": "targets/s", "cores": 1, "kind": "port",
            "sample": "first %d of the targets of set 0 (walk + path search, oracle/km_oracle.py, dict-backed "
                      "table of the %d keys the first %d targets touch)" % (n_sample, _CPU["n_keys"], n_need),
-           "probes_per_s": probes / dt, "seconds": dt}
+           "probes_per_s": probes / dt, "seconds": dt, "cpu_model": cpu_model(),
+           "table_load_s": t_load,
+           "phase_split": {"targets": n_ph, "walk_s": ph[0], "graph_s": ph[1], "naming_quantification_rows_s": ph[2],
+                           "walk_frac": ph[0] / max(1e-12, sum(ph)), "graph_frac": ph[1] / max(1e-12, sum(ph)),
+                           "report_frac": ph[2] / max(1e-12, sum(ph))}}
     try:
         ctx = mp.get_context("fork")
         spans = [(c * per, min(n_need, (c + 1) * per)) for c in range(cores)]
@@ -499,6 +534,32 @@ def main():
                   "host_reader_parse_s": t_parse, "host_reader_plus_upload_s": t_host,
                   "direct_file_to_table_s": t_direct, "direct_GBs": size / t_direct / 1e9}
 
+    # ---- BASELINE config 5: the 9-target catalog x N synthetic per-sample .jf (seed = sample index),
+    #      sample-sharded; every sample = kmjf_load + one batch + native rows (km_amd.dist.sample_matrix)
+    cfg5 = None
+    cat_dir = os.path.join(ROOT, "tests", "data", "catalog", "GRCh38")
+    if rank == 0 and not args.only_step and args.ingest and os.path.isdir(cat_dir) and world == 1:
+        import tempfile
+        from km_amd.cli import read_target
+        files = [os.path.join(cat_dir, f) for f in sorted(os.listdir(cat_dir))]
+        seqs = [read_target(f) for f in files]
+        n_samples, n_sk = 6, 4_000_000
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for si in range(n_samples):
+                kk, cc = synth.make_sample(seqs, si, K, n_sk)
+                pth = os.path.join(td, "sample_%02d.jf" % si)
+                synth.write_jf(pth, kk, cc, K)
+                paths.append(pth)
+            kd.sample_matrix(paths[:1], files, os.path.join(td, "warm"))
+            t_s = time.perf_counter()
+            outs = kd.sample_matrix(paths, files, os.path.join(td, "out"))
+            t_s = time.perf_counter() - t_s
+            n_rows = sum(sum(1 for l in open(o) if not l.startswith("#")) for o in outs)
+        cfg5 = {"samples": n_samples, "keys_per_sample": n_sk, "targets": len(files), "seconds": t_s,
+                "samples_per_s": n_samples / t_s, "tsv_lines": n_rows,
+                "includes": ".jf -> HBM table per sample, one batch over the catalog, native rows, files written"}
+
     # ---- probe kernels alone (rows A2 / A3) ----------------------------------------------------
     probe = None
     if rank == 0 and d_probe is not None and not args.only_step:
@@ -617,6 +678,7 @@ def main():
             "result_fetch_copying_api_ms": fetch_s * 1e3,
             "oracle_check": check,
             "config4_strong": strong,
+            "config5_samples": cfg5,
             "end_to_end_host_path": e2e,
             "single_target_latency": single,
             "probe_kernels": probe,

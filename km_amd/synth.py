@@ -165,6 +165,47 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
             "key_target": tids}
 
 
+def make_sample(target_seqs, seed, k=31, n_keys=2_000_000, cov=(50, 2000), variant_frac=0.5,
+                vaf=(0.1, 0.6), kinds=("snv", "ins", "del", "dup")):
+    """One synthetic SAMPLE for BASELINE config 5: a k-mer count table for a GIVEN
+    catalog of target sequences (strings, any lengths), seed = sample index.  Every target gets a
+    coverage, half of them one variant at a random VAF, and the table is padded with random
+    canonical k-mers to `n_keys`.  Returns (keys uint64, counts uint32), distinct canonical keys."""
+    rng = np.random.default_rng(1000003 * (int(seed) + 1))
+    all_k, all_c = [], []
+    for seq in target_seqs:
+        row = km.encode(seq).astype(np.uint8)
+        if row.size < k or (row > 3).any():
+            continue
+        ref = km.sliding_kmers(row, k)
+        base = int(rng.integers(cov[0], cov[1]))
+        cnt = np.maximum(1, np.rint(base * rng.uniform(0.9, 1.1, size=ref.size))).astype(np.int64)
+        if rng.random() < variant_frac and row.size >= 2 * k + 4:     # room for a variant with k-1 flanks
+            kind = kinds[int(rng.integers(0, len(kinds)))]
+            mut, lo, hi = _mutate(rng, row, kind, k)
+            f = float(rng.uniform(vaf[0], vaf[1]))
+            mk = km.sliding_kmers(mut, k)
+            alt = mk[~np.isin(mk, ref)]
+            if alt.size:
+                all_k.append(alt)
+                all_c.append(np.maximum(1, np.rint(base * f * rng.uniform(0.9, 1.1, size=alt.size))).astype(np.int64))
+                s0, s1 = max(0, lo - k + 1), min(ref.size, max(hi, lo + 1))
+                span = np.arange(s0, s1)
+                span = span[~np.isin(ref[span], mk)]
+                cnt[span] = np.maximum(1, np.rint(cnt[span] * (1.0 - f))).astype(np.int64)
+        all_k.append(ref)
+        all_c.append(cnt)
+    keys = km.canonical(np.concatenate(all_k), k) if all_k else np.zeros(0, np.uint64)
+    cnts = np.concatenate(all_c) if all_c else np.zeros(0, np.int64)
+    n_pad = max(0, n_keys - keys.size)
+    if n_pad:
+        hi = (1 << (2 * k)) if 2 * k < 64 else int(np.iinfo(np.uint64).max)
+        keys = np.concatenate([keys, km.canonical(rng.integers(0, hi, size=n_pad, dtype=np.uint64), k)])
+        cnts = np.concatenate([cnts, rng.integers(2, 51, size=n_pad)])
+    uk, first = np.unique(keys, return_index=True)          # first occurrence wins
+    return uk.astype(np.uint64), np.minimum(cnts[first], 0xFFFFFFFF).astype(np.uint32)
+
+
 def write_jf(path, keys, counts, k, canonical=True):
     """Write keys/counts in the `binary/sorted` record layout our loaders read
     (9-digit length, JSON header, fixed key+count records)."""

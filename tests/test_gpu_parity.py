@@ -895,3 +895,31 @@ def test_cli_two_ranks_target_sharded(tmp_path):
         name = os.path.splitext(os.path.basename(t["target"]))[0]
         got = [l for l in open(str(tmp_path / "m" / (name + ".tsv"))).read().splitlines() if not l.startswith("#Elapsed time")]
         assert got == t["stream"], name
+
+
+def test_config5_synthetic_samples_match_oracle(tmp_path):
+    """BASELINE config 5: the 9-target catalog against synthetic per-sample tables (seed = sample
+    index, km_amd.synth.make_sample) through km_amd.dist.sample_matrix; every row of every
+    per-target stream equals the oracle's find_mutation output for that (target, sample)."""
+    from km_amd import dist as kd
+    cat = sorted(os.listdir("./data/catalog/GRCh38"))
+    files = ["./data/catalog/GRCh38/" + f for f in cat]
+    seqs = [ko.read_fasta_concat(f) for f in files]
+    paths = []
+    for si in range(3):
+        keys, counts = synth.make_sample(seqs, si, 31, 300_000)
+        pth = str(tmp_path / ("sample_%d.jf" % si))
+        synth.write_jf(pth, keys, counts, 31)
+        paths.append(pth)
+    outs = kd.sample_matrix(paths, files, str(tmp_path / "out"))
+    n_var = 0
+    for f, out in zip(files, outs):
+        want = []
+        for pth in paths:
+            lines, err = ko.run_find_mutation([f], pth)
+            assert err is None
+            want += lines
+        got = [l for l in open(out).read().splitlines() if not l.startswith("#Elapsed time")]
+        assert got == want, f
+        n_var += sum(1 for l in got if "\tvs_ref" in l and "\tReference\t" not in l)
+    assert n_var >= 3
