@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t h_status = a.status[t], h_tflag = a.tflag[t];   // header words requested together
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
+  const uint64_t h_woff = a.woff[t];
   if (tid == 0) a.t_refmax[t] = NOT_BARE;      // every target passes here before k_graph sees it
   if (h_status != T_OK) {
     if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     return;
   }
   {
-    const uint64_t* src = a.packed + a.woff[t];
+    const uint64_t* src = a.packed + h_woff;
     for (uint32_t w = tid; w <= nwords; w += NT) words[w] = src[w];
   }
   // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   const uint32_t m = a.n_nodes[t];
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
+  const uint64_t h_woff = a.woff[t];
   if (h_status != T_OK) {
     if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     for (uint64_t x = tid; x < n16; x += NT) q[x] = ones;
   }
   {
-    const uint64_t* srcw = a.packed + a.woff[t];
+    const uint64_t* srcw = a.packed + h_woff;
     for (uint32_t w = tid; w <= nwords; w += NT) words[w] = srcw[w];
   }
   // node j's k-mer: the target's own k-mers come from its packed words

@@ -29,7 +29,8 @@ for n_fl in fls:
         streams.append(kmlib.stream_create(0))
     lean = both | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN
     for flags, name in ((both | kmlib.KM_RUN_DELIVER, "deliver"), (lean, "lean"), (lean | kmlib.KM_RUN_HIPGRAPH, "lean+graph"),
-                        (both, "kernels only"), (both | kmlib.KM_RUN_HIPGRAPH, "kernels+graph")):
+                        (both, "kernels only"), (both | kmlib.KM_RUN_HIPGRAPH, "kernels+graph"),
+                        (kmlib.KM_STAGE_GRAPH, "graph stage only"), (kmlib.KM_STAGE_WALK, "walk stage only")):
         wait = bool(flags & kmlib.KM_RUN_DELIVER)
         for rep in range(2):
             steps = 40
