@@ -498,11 +498,14 @@ def main():
         tg = [(case["names"][i], km.decode(case["targets"][i])) for i in range(n_e)]
         jf = Jellyfish("synthetic.jf", cutoff=0.05, n_cutoff=5, device=local_rank, db=db)
         finder = BatchFinder(jf)
-        finder.rows(tg[:64])                                     # workspace allocation, first launch
-        finder.rows(tg)
+        import io
+        finder.write_rows(tg[:64], io.StringIO())                # workspace allocation, first launch
+        finder.write_rows(tg, io.StringIO())
+        sink = io.StringIO()
         t_e = time.perf_counter()
-        n_rows = sum(len(r) for r in finder.rows(tg))            # native reporting (km_report_rows)
-        e2e = {"targets": n_e, "rows": n_rows, "seconds": time.perf_counter() - t_e}
+        finder.write_rows(tg, sink)                              # what the CLI does per batch (km_report_rows)
+        e2e = {"targets": n_e, "seconds": time.perf_counter() - t_e}
+        e2e["rows"] = sink.getvalue().count("\n")
         e2e["targets_per_s"] = n_e / e2e["seconds"]
 
     # ---- `.jf` ingestion -------------------------------------------------------

@@ -245,7 +245,8 @@ typedef struct {
                                     aux / probes / path_len; node_kmer may be NULL when
                                     extra_off / extra_kmer are given                          */
 } km_report_in_t;
-/* text: the TSV rows of every KM_T_OK target, rows of one target separated by '\n';
+/* text: the TSV rows of every KM_T_OK target, each row terminated by '\n' (the text as a whole is
+ * what `km find_mutation` prints between its header and its trailer);
  * row_off[t] .. row_off[t+1] is the block of target t (empty for other statuses);
  * err[t] != 0 where the reference would have raised while naming a variant
  * (1 IndexError, 2 "mutation identification could be incorrect", 3 AssertionError,

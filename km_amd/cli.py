@@ -127,11 +127,14 @@ def main_find_mut(args, out=None, err=None):
     finder = BatchFinder(jf, args.steps, args.branchs, args.nodes)
     for lo in range(0, len(targets), CHUNK):
         part = targets[lo:lo + CHUNK]
-        blocks = finder.rows(part)                 # native reporting (km_report_rows)
+        try:
+            finder.write_rows(part, out)           # native reporting (km_report_rows), one write per batch
+        except NodeLimitExceeded as e:
+            sys.exit(str(e))
         if args.verbose or args.debug:
             for t in range(len(part)):
                 _verbose_lines(part[t], finder.last_raw, t, jf.k, err)
-        _print_rows(blocks, out)
+        out.flush()
     out.write("#Elapsed time:" + str(time.time() - t0) + "\n")
 
 

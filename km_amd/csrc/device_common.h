@@ -423,11 +423,17 @@ struct PendingLookup {
   uint64_t S, idx;
   uint4 a0, a1;
   bool valid;
+#ifdef KM_DFS_STAMPS
+  unsigned long long t_key;   // diagnostics: shader clock after the key was computed
+#endif
 };
 __device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCache* dc,
                                            PendingLookup* p) {
   p->X = X;
   p->g = make_key_wave(t, X & t.pmask);
+#ifdef KM_DFS_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p->t_key)::"memory");
+#endif
   if (p->g.bucket != dc->bucket) {
     const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + p->g.bucket);
     dc->bucket = p->g.bucket; dc->lo = d.lo; dc->hi = d.hi;
@@ -436,14 +442,26 @@ __device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCa
   p->base = t.slots + 2ull * dc->lo;
   p->idx = home_slot(t, p->g, p->S);
   const Slot* b0 = (p->S ? p->base : t.slots) + p->idx;
-  p->a0 = *reinterpret_cast<const uint4*>(b0);
-  p->a1 = *reinterpret_cast<const uint4*>(b0 + 1);
+  // The address is wave-uniform, but the request must stay a VECTOR load whose result is not
+  // looked at before children_finish_wave: given a uniform address the compiler moves the eight
+  // loaded words to scalar registers at once, i.e. waits for the memory right here, and the
+  // latency the early request was meant to hide is paid in full.  A lane offset it cannot see
+  // through (always 0) keeps the words in vector registers until they are needed.
+  uint32_t lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  const uint4* q = reinterpret_cast<const uint4*>(b0) + lane_zero;
+  p->a0 = q[0];
+  p->a1 = q[1];
   p->valid = true;
+}
+__device__ inline uint4 uniform4(uint4 v) {
+  return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y),
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w));
 }
 __device__ inline uint4 children_finish_wave(const TableView& t, const PendingLookup& p,
                                              uint32_t* fetches) {
   uint4 c = make_uint4(0, 0, 0, 0);
-  if (p.S) c = bucket_resolve2(t, p.g, p.base, p.S, p.idx, p.a0, p.a1, fetches);
+  if (p.S) c = bucket_resolve2(t, p.g, p.base, p.S, p.idx, uniform4(p.a0), uniform4(p.a1), fetches);
   return finish_children(t, p.X, p.g.flip, c);
 }
 __device__ inline uint4 forward_children_wave(const TableView& t, uint64_t X, DirCache* dc,

@@ -583,8 +583,8 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
           if (g_tie) err[ti] = 100;                    // rows are still delivered
           std::string& out = block[ti];
           for (size_t i = 0; i < rows.size(); ++i) {
-            if (i) out.push_back('\n');
             out += rows[i];
+            out.push_back('\n');                     // every row is terminated: blocks concatenate into the TSV
           }
         }
       } catch (...) {

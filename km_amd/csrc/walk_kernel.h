@@ -150,6 +150,20 @@ __device__ inline int set_insert_lane(uint64_t* keys, uint32_t cap, uint64_t key
   return -1;
 }
 
+// Per-lane lookup (every lane its own key, no writers meanwhile): the slot of the key (*found)
+// or the empty slot that ends its probe sequence; -1 if the set is full of other keys.
+__device__ inline int set_lookup_lane(const uint64_t* keys, uint32_t cap, uint64_t key, bool* found) {
+  uint32_t s = set_home(key, cap);
+  for (uint32_t step = 0; step < cap; ++step) {
+    const uint64_t kv = keys[s];
+    if (kv == key) { *found = true; return (int)s; }
+    if (kv == EMPTY) { *found = false; return (int)s; }
+    if (++s == cap) s = 0;
+  }
+  *found = false;
+  return -1;
+}
+
 // Wave-cooperative lookup (all 64 lanes call with the same key).  Returns the
 // slot of the key (*found) or the empty slot where it would be inserted.
 __device__ inline int set_find(const uint64_t* keys, uint32_t cap, uint64_t key, bool* found) {
@@ -439,6 +453,20 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
 }
 
 // ---------------------------------------------------------------------------- k_dfs
+// Diagnostics build only (-DKM_DFS_STAMPS, tools/dfs_stamps.py): shader-clock time of the
+// sections of a DFS step, summed per wave in scalar registers.
+#ifdef KM_DFS_STAMPS
+#define KM_DFS_STAMP(n)                                                                       \
+  do {                                                                                        \
+    unsigned long long t_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    dfs_acc[n] += (uint32_t)t_ - dfs_prev;                                                    \
+    dfs_prev = (uint32_t)t_;                                                                  \
+  } while (0)
+#else
+#define KM_DFS_STAMP(n) do {} while (0)
+#endif
+
 template <bool BIG, int K>
 __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -520,6 +548,14 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
+#ifdef KM_DFS_STAMPS
+  uint32_t dfs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dfs_prev, dfs_t0, dfs_steps = 0;   // 32 bits: few SGPRs
+  {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    dfs_t0 = dfs_prev = (uint32_t)t_;
+  }
+#endif
 
   // ---- exact DFS from every flagged seed, in target order ----------------------------
   if (st == T_OK) {
@@ -542,11 +578,14 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         step_sync();
         while (true) {
           if (++steps > DFS_STEP_LIMIT) { st = T_INTERNAL; break; }
+          KM_DFS_STAMP(0);                                 // loop control + whatever was not stamped
           if (need_expand) {
             need_expand = false;
             if (n_nodes > a.max_node) { st = T_NODE_LIMIT; break; }
             if (!(pend.valid && pend.X == cur)) children_issue_wave(tab, cur, &dcache, &pend);
+            KM_DFS_STAMP(1);                               // a lookup that had not been requested ahead
             c4 = children_finish_wave(tab, pend, &fetch_u);
+            KM_DFS_STAMP(2);                               // wait for the pair + resolve
             pend.valid = false;
             probes_u += 4;
             mask = child_mask(c4, a.ratio, a.n_cutoff);
@@ -555,10 +594,118 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               ++brk;
               if (brk > a.max_break) mask = 0;
             }
+            KM_DFS_STAMP(8);                               // thresholds
             // the walk most likely continues with the first kept child: request its lookup
             // now, its latency overlaps the bookkeeping of this step
-            if (mask && depth + 1 <= a.max_stack)
+            if (mask && depth + 1 <= a.max_stack) {
               children_issue_wave(tab, ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask, &dcache, &pend);
+#ifdef KM_DFS_STAMPS
+              dfs_acc[9] += (uint32_t)pend.t_key - dfs_prev;   // key of the next lookup
+              dfs_prev = (uint32_t)pend.t_key;
+#endif
+            }
+            KM_DFS_STAMP(3);                               // directory word, home pair, request                               // thresholds + key and request of the next lookup
+#ifdef KM_DFS_STAMPS
+            ++dfs_steps;
+#endif
+          }
+          // ---- chain run.  cur has exactly one child left to take.  As long as that keeps
+          // being so, only the lookups depend on each other; the node-set probe, the insertion
+          // and the stack frame of every child on the chain do not, so the chain is walked with
+          // the lookups alone (child j of the run recorded in lane j) and booked afterwards by
+          // all lanes at once.  The run assumes every child to be new; the booking finds the
+          // first one that is not (a rejoin or a loop), keeps what precedes it and hands that
+          // child to the general step below, which treats it exactly as before.  What was
+          // looked up past it is dropped: lookups have no side effects.
+          if (mask != 0 && (mask & (mask - 1)) == 0 && n_nodes <= a.max_node) {
+            int64_t room64 = 64;
+            room64 = min(room64, (int64_t)a.max_stack - (int64_t)depth);
+            room64 = min(room64, (int64_t)a.fcap - (int64_t)depth);
+            room64 = min(room64, (int64_t)set_limit - (int64_t)set_count);
+            const uint32_t room = room64 > 0 ? (uint32_t)room64 : 0u;
+            uint32_t n = 0;
+            uint64_t rkey = 0;                             // lane j: child j of the run
+            uint32_t rcnt = 0;
+            uint64_t x = cur;
+            uint4 xc4 = c4;
+            uint32_t xm = mask;
+            while (n < room) {
+              const uint32_t c = (uint32_t)__ffs((int)xm) - 1;
+              const uint64_t child = ((x << 2) | c) & tab.kmask;
+              // a child that sits in its home slot of the node set is (most likely) a rejoin:
+              // stop here and let the general step decide.  Only a hint — misses are caught below.
+              const uint64_t at_home = keys[set_home(child, cap)];
+              if (!(pend.valid && pend.X == child)) children_issue_wave(tab, child, &dcache, &pend);
+              if (at_home == child) break;
+              const uint32_t cnt = pick4(xc4, c);
+              if (lane == n) { rkey = child; rcnt = cnt; }
+              ++n;
+              xc4 = children_finish_wave(tab, pend, &fetch_u);
+              pend.valid = false;
+              xm = child_mask(xc4, a.ratio, a.n_cutoff);
+              x = child;
+              if (xm == 0 || (xm & (xm - 1)) != 0) break;
+            }
+            if (n) {
+              steps += n;
+              // ---- booking: first child of the run that is already a node or on the stack
+              const bool act = lane < n;
+              bool found = false;
+              int slot = -1;
+              uint32_t st8 = 0;
+              if (act) {
+                slot = set_lookup_lane(keys, cap, rkey, &found);
+                if (found) st8 = state[slot];
+              }
+              bool stop = act && (slot < 0 || (found && (st8 == ST_NODE || st8 == ST_ONSTACK)));
+              for (uint32_t i = 0; i + 1 < n; ++i) {       // ... or repeats an earlier child of the run
+                const uint64_t ki = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(rkey >> 32), (int)i) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, (int)i);
+                stop = stop || (act && lane > i && rkey == ki);
+              }
+              const unsigned long long stops = __ballot(stop);
+              const uint32_t f = stops ? (uint32_t)__ffsll((long long)stops) - 1 : n;
+              bool fresh = false;
+              if (lane < f) {
+                if (!found) {
+                  slot = set_insert_lane(keys, cap, rkey, &fresh);
+                }
+                if (slot >= 0) {
+                  state[slot] = (uint8_t)ST_ONSTACK;
+                  fk[depth + lane] = rkey; fc[depth + lane] = rcnt; fs[depth + lane] = (uint32_t)slot;
+                }
+              }
+              if (__any((int)(lane < f && slot < 0))) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
+              set_count += (uint32_t)__popcll(__ballot(fresh));
+              probes_u += 4ull * f;
+              parent_brk = brk;
+              if (f == n) {
+                // the whole run stands: x is the top of the stack, (xc4, xm) its expansion
+                depth += n;
+                cur = x;
+                c4 = xc4;
+                mask = xm;
+                if (__popc(mask) > 1) {
+                  ++brk;
+                  if (brk > a.max_break) mask = 0;
+                }
+                if (mask && depth + 1 <= a.max_stack && !(pend.valid && pend.X == (((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask)))
+                  children_issue_wave(tab, ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask, &dcache, &pend);
+              } else {
+                // child f is not new: its parent (child f - 1, or cur) is the top of the stack and
+                // has exactly this child left
+                const uint64_t kf = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(rkey >> 32), (int)f) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, (int)f);
+                const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)rcnt, (int)f);
+                depth += f;
+                if (f) cur = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(rkey >> 32), (int)(f - 1)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, (int)(f - 1));
+                c4 = make_uint4(cf, cf, cf, cf);
+                mask = 1u << (uint32_t)(kf & 3);
+                pend.valid = false;
+              }
+              step_sync();
+            }
           }
           if (mask == 0) {
             if (bsp == 0) break;                         // DFS from this seed is done
@@ -574,6 +721,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             cur = fk[depth - 1];
             c4 = f.c4; mask = f.mask; brk = f.brk;
             step_sync();
+            KM_DFS_STAMP(4);                               // unwind to a branch frame
             continue;
           }
           const uint32_t c = (uint32_t)__ffs((int)mask) - 1;
@@ -584,6 +732,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           int slot = set_find(keys, cap, child, &found);
           if (slot < 0) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
           const uint32_t stt = found ? (uint32_t)state[slot] : 0u;
+          KM_DFS_STAMP(5);                                 // node-set probe of the child
           if (found && (stt == ST_NODE || stt == ST_ONSTACK)) {
             // rejoin (or loop): for p in stack: node_data[p] = jf.query(p)
             probes_u += depth;
@@ -600,6 +749,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               reg = depth;
               step_sync();
             }
+            KM_DFS_STAMP(6);                               // rejoin: register the stack
           } else if (depth + 1 <= a.max_stack) {
             // __extend(stack + [child], breaks)
             if (!found && set_count + 1 > set_limit) {
@@ -648,6 +798,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             cur = child;
             need_expand = true;
             step_sync();
+            KM_DFS_STAMP(7);                               // push
           }
           // else: the child's __extend returns at once (len(stack) > max_stack)
         }
@@ -665,6 +816,17 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     }
   }
 
+#ifdef KM_DFS_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long tend;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
+    unsigned long long* o = a.stamps + 16ull * blockIdx.x;
+    for (int q = 0; q < 8; ++q) o[q] = dfs_acc[q];
+    o[8] = dfs_steps; o[9] = (uint32_t)tend - dfs_t0; o[10] = t; o[11] = probes_u;
+    o[12] = dfs_acc[8]; o[13] = dfs_acc[9];
+    o[15] = 0x6466735f7374616dull;                         // record marker
+  }
+#endif
   if (lane == 0) {
     a.status[t] = st;
     if (st != T_NEEDS_BIG) {     // a large-tier rerun restarts from the seed kernel's counters

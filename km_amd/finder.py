@@ -91,6 +91,41 @@ class BatchFinder:
                 out[t] = NodeLimitExceeded(self.max_node)
         return out
 
+    def write_rows(self, targets, out, db_name=None):
+        """`rows`, written straight to the stream `out`: when no target of the batch needs special
+        handling the native text IS the TSV body and goes out in one write.  Stops like the
+        reference at a node-limit exit / naming exception (after the rows of the earlier targets)."""
+        names = [t[0] for t in targets]
+        seqs = [t[1] for t in targets]
+        packed = _lib.pack_sequences(seqs)
+        b = self._ensure(len(seqs), int(packed[1][-1]))
+        b.set_targets_packed(*packed)
+        b.run(_lib.KM_STAGE_WALK | _lib.KM_STAGE_GRAPH | _lib.KM_RUN_DELIVER | _lib.KM_DELIVER_LEAN)
+        raw = b.result()
+        self.last_raw = raw
+        self._raise_input_errors(raw, names, seqs)
+        text, row_off, special = _lib.report_text(raw, names, seqs, self.jf.k,
+                                                  self.jf.filename if db_name is None else db_name, packed=packed)
+        limit = np.nonzero(raw["status"] == _lib.T_NODE_LIMIT)[0]
+        if not special and limit.size == 0:
+            out.write(text)
+            return
+        stops = sorted(set(special) | set(limit.tolist()))
+        pos = 0
+        for t in stops:
+            out.write(text[int(row_off[pos]):int(row_off[t])])
+            pos = t + 1
+            if raw["status"][t] == _lib.T_NODE_LIMIT:
+                out.flush()
+                raise NodeLimitExceeded(self.max_node)
+            blk = special[t]
+            if isinstance(blk, BaseException):
+                out.flush()
+                raise blk
+            for row in blk:
+                out.write(row + "\n")
+        out.write(text[int(row_off[pos]):])
+
     def analyse(self, targets):
         """targets: list of (name, seq).  Returns a list with one TargetResult per
         target, or the exception the reference would have raised at that target."""

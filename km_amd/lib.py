@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmgpu.so")
+# KM_LIBRARY: another build of the same library (diagnostics builds of tools/); it must exist
+LIB_PATH = os.environ.get("KM_LIBRARY") or os.path.join(_HERE, "libkmgpu.so")
 
 KM_OK = 0
 KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER, KM_DELIVER_LEAN, KM_RUN_TIMED = 1, 2, 4, 8, 16, 32
@@ -490,6 +491,22 @@ def report_rows(res, names, seqs, k, db_name, packed=None):
     reporting path: returns a list with, per target, a list of row strings (empty unless the
     target's status is KM_T_OK) or the exception the reference would have raised.
     `packed` = pack_sequences(seqs) when the caller already has it."""
+    text, row_off, special = report_text(res, names, seqs, k, db_name, packed)
+    result = []
+    for t in range(len(names)):
+        if t in special:
+            result.append(special[t])
+        else:
+            a, e = int(row_off[t]), int(row_off[t + 1])
+            result.append(text[a:e].splitlines() if e > a else [])
+    return result
+
+
+def report_text(res, names, seqs, k, db_name, packed=None):
+    """The same as one string: (text, row_off, special).  text[row_off[t]:row_off[t+1]] is the block
+    of target t, every row terminated by a newline; `special` maps the few targets that are NOT
+    served by the text to their row list (numpy recomputation on a rounding tie) or to the exception
+    the reference would have raised.  When `special` is empty, `text` is the whole TSV body."""
     lib = load()
     n = len(names)
     blob, offs = packed if packed is not None else pack_sequences(seqs)
@@ -523,18 +540,16 @@ def report_rows(res, names, seqs, k, db_name, packed=None):
     try:
         total = int(row_off[n])
         blob_out = C.string_at(text, total).decode("ascii")
-        result = []
-        for t in range(n):
-            if err[t] == 100:
+        offs_out = np.ctypeslib.as_array(row_off, shape=(n + 1,)).copy()
+        errs = np.ctypeslib.as_array(err, shape=(max(1, n),))[:n]
+        special = {}
+        for t in np.nonzero(errs)[0].tolist():
+            if errs[t] == 100:
                 # a printed value sits on a %.1f / %.3f rounding tie: the digit depends on the
                 # last bits of the least-squares solver — recompute with numpy, like the reference
-                result.append(_python_rows(res, t, names[t], seqs[t], k, db_name))
-                continue
-            if err[t]:
-                result.append(REPORT_ERRORS.get(int(err[t]), RuntimeError("report error %d" % err[t])))
-                continue
-            a, e = int(row_off[t]), int(row_off[t + 1])
-            result.append(blob_out[a:e].split("\n") if e > a else [])
+                special[t] = _python_rows(res, t, names[t], seqs[t], k, db_name)
+            else:
+                special[t] = REPORT_ERRORS.get(int(errs[t]), RuntimeError("report error %d" % errs[t]))
     finally:
         lib.km_report_free(text, row_off, err)
-    return result
+    return blob_out, offs_out, special

@@ -74,7 +74,6 @@ int main(int argc, char** argv) {
   int32_t* err = NULL;
   CHECK(km_report_rows(&in, &text, &row_off, &err));
   fwrite(text, 1, (size_t)row_off[1], stdout);
-  fputc('\n', stdout);
   fprintf(stderr, "nodes %llu paths %u logical probes %llu report flag %d\n", (unsigned long long)sz.n_nodes,
           sz.n_paths, (unsigned long long)sz.logical_probes, err[0]);
   km_report_free(text, row_off, err);

@@ -25,6 +25,14 @@ finder.rows(tg[:64])
 t = time.perf_counter()
 rows = finder.rows(tg)
 print("e2e %.1f ms for %d targets, %d rows" % ((time.perf_counter() - t) * 1e3, n, sum(len(r) for r in rows)))
+import io
+for _ in range(3):
+    sink = io.StringIO()
+    t = time.perf_counter()
+    finder.write_rows(tg, sink)
+    dt = time.perf_counter() - t
+print("write_rows %.1f ms for %d targets, %d rows (%.0f targets/s)"
+      % (dt * 1e3, n, sink.getvalue().count("\n"), n / dt))
 pr = cProfile.Profile()
 pr.enable()
 finder.rows(tg)
