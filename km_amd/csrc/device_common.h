@@ -167,6 +167,9 @@ __host__ __device__ inline uint32_t window_key(const TableView& t, uint64_t P, u
   return (mm_order(c) & ~SEL_POS) | (uint32_t)j;
 }
 
+__host__ __device__ inline uint32_t bucket_of(const TableView& t, uint32_t canon_mmer) {
+  return (uint32_t)(((uint64_t)mm_bucket(canon_mmer) * t.n_buckets) >> 32);
+}
 __host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint64_t R, uint32_t c,
                                            uint32_t s, uint32_t u, Key* key) {
   if (!t.canonical || P <= R) {
@@ -176,7 +179,7 @@ __host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint6
     key->tag = (R << 1) | 1;
     key->flip = 1;
   }
-  key->bucket = (uint32_t)(((uint64_t)mm_bucket(c) * t.n_buckets) >> 32);
+  key->bucket = bucket_of(t, c);
   // walking forward along a strand moves the minimizer one base to the left: u falls, cls rises
   const uint32_t cls = s * (uint32_t)t.w + ((uint32_t)t.w - 1u - u);
   // every bit of the tag takes part: (k-1)-mers that differ only in their first bases (left
@@ -238,8 +241,10 @@ __device__ inline uint64_t kmer_from_words(const uint64_t* words, uint32_t i, in
 
 // The same key for a wave-uniform P with the windows spread over the lanes (k_dfs: one
 // lookup per walk step, latency matters).  Every lane returns the full key.
-__device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
-  const uint64_t R = revcomp(P, t.k - 1);
+// best = selection key of the minimizer window (its position in the low bits), bc / bs = its
+// canonical m-mer and strand.
+__device__ inline void minimizer_wave(const TableView& t, uint64_t P, uint64_t R, uint32_t* best_out,
+                                      uint32_t* bc_out, uint32_t* bs_out) {
   const int lane = lane_id();
   uint32_t c = 0, s = 0;
   uint32_t mine = ~0u;
@@ -258,10 +263,16 @@ __device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
   const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
   const uint32_t best = b0 < b1 ? b0 : b1;
   const int u = (int)(best & SEL_POS);
-  const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, u);
-  const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)s, u);
+  *best_out = best;
+  *bc_out = (uint32_t)__builtin_amdgcn_readlane((int)c, u);
+  *bs_out = (uint32_t)__builtin_amdgcn_readlane((int)s, u);
+}
+__device__ inline Key make_key_wave(const TableView& t, uint64_t P) {
+  const uint64_t R = revcomp(P, t.k - 1);
+  uint32_t best, bc, bs;
+  minimizer_wave(t, P, R, &best, &bc, &bs);
   Key key;
-  finish_key(t, P, R, bc, bs, (uint32_t)u, &key);
+  finish_key(t, P, R, bc, bs, best & SEL_POS, &key);
   return key;
 }
 
@@ -454,6 +465,89 @@ __device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCa
   p->a1 = q[1];
   p->valid = true;
 }
+// The same request for the next k-mer of a CHAIN (k_dfs walking a run of single children): the
+// key of child = x[1:] + c follows from the key state of x with a handful of scalar operations.
+// The reverse complement shifts in one base; of the w windows only the last one is new, so the
+// minimizer is the old one moved one position to the left unless the new window beats it — or
+// the old one has just left the k-mer (one step in ~w), which costs the full wave-wide search.
+struct ChainKey {
+  uint64_t R;        // revcomp of the (k-1)-mer whose group was requested last
+  uint32_t best;     // selection key of its minimizer (position in the low bits)
+  uint32_t bc, bs;   // canonical m-mer and strand of the minimizer
+  uint32_t bucket;
+  bool valid;
+};
+template <int K>
+__device__ inline void chain_issue_wave(const TableView& t, ChainKey* ck, uint64_t child, uint32_t c,
+                                        DirCache* dc, PendingLookup* p) {
+  const uint64_t P = child & t.pmask;
+  uint64_t R;
+  uint32_t best = 0, bc = 0, bs = 0, bucket = 0;
+  bool searched = false;
+  if (K != 0 && ck->valid) {
+    R = (ck->R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
+    if ((ck->best & SEL_POS) != 0) {
+      const uint32_t f = (uint32_t)P & t.mmask;
+      const uint32_t r = (uint32_t)(R >> (2 * (t.w - 1))) & t.mmask;
+      const uint32_t cn = f < r ? f : r;
+      const uint32_t seln = (mm_order(cn) & ~SEL_POS) | (uint32_t)(t.w - 1);
+      best = ck->best - 1u;                      // same window, one position further left
+      bc = ck->bc; bs = ck->bs; bucket = ck->bucket;
+      if (seln < best) {
+        best = seln; bc = cn; bs = f < r ? 0u : 1u;
+        bucket = bucket_of(t, bc);
+      }
+      searched = true;
+    }
+  } else {
+    R = revcomp(P, t.k - 1);
+  }
+  if (!searched) {
+    minimizer_wave(t, P, R, &best, &bc, &bs);
+    bucket = bucket_of(t, bc);
+  }
+  ck->R = R; ck->best = best; ck->bc = bc; ck->bs = bs; ck->bucket = bucket; ck->valid = true;
+  Key g;
+  finish_key(t, P, R, bc, bs, best & SEL_POS, &g);
+  g.bucket = bucket;
+  p->X = child;
+  p->g = g;
+#ifdef KM_DFS_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p->t_key)::"memory");
+#endif
+  if (bucket != dc->bucket) {
+    const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + bucket);
+    dc->bucket = bucket; dc->lo = d.lo; dc->hi = d.hi;
+  }
+  p->S = bucket_slots(dc->lo, dc->hi);
+  p->base = t.slots + 2ull * dc->lo;
+  p->idx = home_slot(t, p->g, p->S);
+  const Slot* b0 = (p->S ? p->base : t.slots) + p->idx;
+  uint32_t lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  const uint4* q = reinterpret_cast<const uint4*>(b0) + lane_zero;
+  p->a0 = q[0];
+  p->a1 = q[1];
+  p->valid = true;
+}
+
+// Counts of the group requested in p as the two count words of its slot (four u16 in slot order),
+// when the home pair settles it (the normal case).  false: the search has to go past the pair.
+__device__ inline uint64_t uniform64(uint32_t lo, uint32_t hi) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+}
+__device__ inline bool chain_counts_packed(const PendingLookup& p, uint64_t* zw, uint32_t* fetches) {
+  if (p.S == 0) { *zw = 0; return true; }
+  const uint64_t t0 = uniform64(p.a0.x, p.a0.y);
+  if (t0 == p.g.tag) { *zw = uniform64(p.a0.z, p.a0.w); *fetches += 1; return true; }
+  if (t0 == EMPTY) { *zw = 0; *fetches += 1; return true; }
+  const uint64_t t1 = uniform64(p.a1.x, p.a1.y);
+  if (t1 == p.g.tag) { *zw = uniform64(p.a1.z, p.a1.w); *fetches += 2; return true; }
+  if (t1 == EMPTY) { *zw = 0; *fetches += 2; return true; }
+  return false;
+}
+
 __device__ inline uint4 uniform4(uint4 v) {
   return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y),
                     (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w));
@@ -492,15 +586,39 @@ __device__ inline uint32_t query_one(const TableView& t, uint64_t X, uint32_t* f
 // Children kept by Jellyfish.get_child: count >= max(sum * cutoff, n_cutoff)
 // evaluated as Python does (float64 product, exact int/float comparison):
 // km/utils/Jellyfish.py:69-72.  Returns a 4-bit mask, bit c = child base c.
-__device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) {
-  const double t = (double)((uint64_t)c.x + c.y + c.z + c.w) * ratio;
+// The threshold as an integer: a count is kept iff it is >= T, unless *none (the threshold lies
+// above every 32-bit count, or is NaN).
+__host__ __device__ inline uint32_t child_threshold(uint64_t sum, double ratio, int64_t n_cutoff, bool* none) {
+  const double t = (double)sum * ratio;
   const double nc = (double)n_cutoff;
   const double thr = (nc > t) ? nc : t;     // Python max(t, nc)
   // an integer count is >= thr  <=>  it is >= ceil(thr): four integer compares
   const double ct = ceil(thr);
-  if (!(ct < 4294967296.0)) return 0u;      // above every 32-bit count (or NaN): none kept
-  const uint32_t T = ct <= 0.0 ? 0u : (uint32_t)ct;
+  *none = !(ct < 4294967296.0);
+  return ct <= 0.0 ? 0u : (*none ? 0xFFFFFFFFu : (uint32_t)ct);
+}
+__device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) {
+  bool none;
+  const uint32_t T = child_threshold((uint64_t)c.x + c.y + c.z + c.w, ratio, n_cutoff, &none);
+  if (none) return 0u;
   return (c.x >= T ? 1u : 0u) | (c.y >= T ? 2u : 0u) | (c.z >= T ? 4u : 0u) | (c.w >= T ? 8u : 0u);
+}
+// Sums below *below* all have the threshold T = ceil(n_cutoff) (sum * ratio <= n_cutoff: the float64
+// product is monotone in the sum for ratio >= 0), so that a walk step can skip the float64 arithmetic
+// for them.  0 = no such shortcut (negative or NaN ratio).
+__host__ inline void threshold_shortcut(double ratio, int64_t n_cutoff, uint64_t* below, uint32_t* T) {
+  *below = 0; *T = 0;
+  if (!(ratio >= 0.0) || ratio > 1.7e308) return;
+  const double nc = (double)n_cutoff;
+  auto same = [&](uint64_t sum) { return (double)sum * ratio <= nc; };
+  if (!same(0)) return;
+  uint64_t lo = 0, hi = 1ull << 36;                      // sums of four 32-bit counts stay below 2^34
+  if (same(hi)) lo = hi;
+  else while (hi - lo > 1) { const uint64_t mid = lo + (hi - lo) / 2; if (same(mid)) lo = mid; else hi = mid; }
+  bool none;
+  const uint32_t t = child_threshold(0, ratio, n_cutoff, &none);
+  if (none) return;
+  *below = lo + 1; *T = t;
 }
 
 }  // namespace kmd

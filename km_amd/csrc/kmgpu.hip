@@ -964,6 +964,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.n_targets = b->n_targets;
   a.ratio = b->p.ratio;
   a.n_cutoff = b->p.count;
+  threshold_shortcut(a.ratio, a.n_cutoff, &a.thr_below, &a.thr_T);
   a.max_stack = b->p.max_stack;
   a.max_break = b->p.max_break;
   a.max_node = b->p.max_node;

@@ -64,6 +64,8 @@ struct WalkArgs {
   uint32_t n_targets;
   double ratio;
   int64_t n_cutoff;
+  uint64_t thr_below;         // sums < thr_below have the threshold thr_T (device_common.h: threshold_shortcut)
+  uint32_t thr_T;
   uint32_t max_stack, max_break, max_node;
   // k_seed work items: one self-contained 128-byte record per SEED_BLOCK seeds, written
   // by k_pack: [0] target | first seed << 32, [1] n_ref | valid << 32, [2] node base,
@@ -626,28 +628,84 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             uint32_t n = 0;
             uint64_t rkey = 0;                             // lane j: child j of the run
             uint32_t rcnt = 0;
-            uint64_t x = cur;
-            uint4 xc4 = c4;
-            uint32_t xm = mask;
+            uint64_t x = cur;                              // top of the (virtual) stack
+            uint32_t c = (uint32_t)__ffs((int)mask) - 1;   // its one child left, and that child's count
+            uint32_t cnt = pick4(c4, c);
+            bool expanded = false;                         // (c4, mask) = a finished expansion of x
+            ChainKey ck;
+            ck.valid = false;
+            const uint32_t lane3 = lane & 3u;
             while (n < room) {
-              const uint32_t c = (uint32_t)__ffs((int)xm) - 1;
               const uint64_t child = ((x << 2) | c) & tab.kmask;
               // a child that sits in its home slot of the node set is (most likely) a rejoin:
               // stop here and let the general step decide.  Only a hint — misses are caught below.
               const uint64_t at_home = keys[set_home(child, cap)];
-              if (!(pend.valid && pend.X == child)) children_issue_wave(tab, child, &dcache, &pend);
+              chain_issue_wave<K>(tab, &ck, child, c, &dcache, &pend);
+#ifdef KM_DFS_STAMPS
+              dfs_acc[9] += (uint32_t)pend.t_key - dfs_prev;
+              dfs_prev = (uint32_t)pend.t_key;
+#endif
+              KM_DFS_STAMP(3);
+#ifdef KM_DFS_STAMPS_CALIBRATE
+              KM_DFS_STAMP(4);                             // back to back: the cost of a stamp itself ("unwind")
+#endif
               if (at_home == child) break;
-              const uint32_t cnt = pick4(xc4, c);
               if (lane == n) { rkey = child; rcnt = cnt; }
               ++n;
-              xc4 = children_finish_wave(tab, pend, &fetch_u);
-              pend.valid = false;
-              xm = child_mask(xc4, a.ratio, a.n_cutoff);
               x = child;
-              if (xm == 0 || (xm & (xm - 1)) != 0) break;
+              // ---- the expansion of child: counts as the slot's two count words when the home
+              // pair settles the lookup and no count is escaped; the thresholds on four lanes
+              uint64_t zw;
+              uint32_t f_add = 0;
+              bool packed_ok = chain_counts_packed(pend, &zw, &f_add);
+              uint32_t cl = 0, xm = 0;
+              const uint32_t flip3 = pend.g.flip ? 3u : 0u;
+              if (packed_ok) {
+                cl = (uint32_t)(zw >> ((lane3 ^ flip3) << 4)) & 0xFFFFu;   // lane i < 4: count of child base i
+                packed_ok = (__ballot(cl == COUNT_ESCAPE) & 0xFull) == 0;
+              }
+              KM_DFS_STAMP(2);
+              if (packed_ok) {
+                fetch_u += f_add;
+                pend.valid = false;
+                const uint32_t z = (uint32_t)zw, w = (uint32_t)(zw >> 32);
+                const uint64_t sum = (uint64_t)((z & 0xFFFFu) + (z >> 16) + (w & 0xFFFFu) + (w >> 16));
+                uint32_t T = a.thr_T;
+                if (sum >= a.thr_below) {
+                  bool none;
+                  T = child_threshold(sum, a.ratio, a.n_cutoff, &none);   // none: T above every u16
+                }
+                xm = (uint32_t)(__ballot(cl >= T) & 0xFull);
+                KM_DFS_STAMP(8);
+                if (xm != 0 && (xm & (xm - 1)) == 0) {
+                  c = (uint32_t)__ffs((int)xm) - 1;
+                  cnt = (uint32_t)(zw >> ((c ^ flip3) << 4)) & 0xFFFFu;
+                  continue;
+                }
+                c4 = make_uint4((uint32_t)(zw >> ((0u ^ flip3) << 4)) & 0xFFFFu, (uint32_t)(zw >> ((1u ^ flip3) << 4)) & 0xFFFFu,
+                                (uint32_t)(zw >> ((2u ^ flip3) << 4)) & 0xFFFFu, (uint32_t)(zw >> ((3u ^ flip3) << 4)) & 0xFFFFu);
+              } else {
+                c4 = children_finish_wave(tab, pend, &fetch_u);
+                pend.valid = false;
+                xm = child_mask(c4, a.ratio, a.n_cutoff);
+                KM_DFS_STAMP(8);
+              }
+              mask = xm;
+              expanded = true;
+              break;
             }
+            if (!expanded) {
+              // x still has its one child c to take (no room left, or the hint): all the general
+              // step needs of the expansion is that child's count
+              c4 = make_uint4(cnt, cnt, cnt, cnt);
+              mask = 1u << c;
+            }
+            const uint64_t x_end = x;
             if (n) {
               steps += n;
+#ifdef KM_DFS_STAMPS
+              dfs_steps += n;
+#endif
               // ---- booking: first child of the run that is already a node or on the stack
               const bool act = lane < n;
               bool found = false;
@@ -680,11 +738,9 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               probes_u += 4ull * f;
               parent_brk = brk;
               if (f == n) {
-                // the whole run stands: x is the top of the stack, (xc4, xm) its expansion
+                // the whole run stands: x is the top of the stack, (c4, mask) its expansion
                 depth += n;
-                cur = x;
-                c4 = xc4;
-                mask = xm;
+                cur = x_end;
                 if (__popc(mask) > 1) {
                   ++brk;
                   if (brk > a.max_break) mask = 0;
@@ -705,6 +761,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 pend.valid = false;
               }
               step_sync();
+              KM_DFS_STAMP(7);                             // booking of a run
             }
           }
           if (mask == 0) {

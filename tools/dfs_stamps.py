@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "km_amd", "csrc")
 so = os.path.join(tempfile.gettempdir(), "libkmgpu_dfs_stamps.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-ffp-contract=off", "-pthread", "-DKM_DFS_STAMPS", "-o", so,
+                       "-ffp-contract=off", "-pthread", "-DKM_DFS_STAMPS"] + (["-DKM_DFS_STAMPS_CALIBRATE"] if os.environ.get("CALIBRATE") else []) + ["-o", so,
                        os.path.join(CSRC, "kmgpu.hip"), os.path.join(CSRC, "jf_reader.cpp"),
                        os.path.join(CSRC, "report.cpp")], cwd=ROOT)
 os.environ["KM_LIBRARY"] = so
