@@ -477,14 +477,16 @@ struct ChainKey {
   uint32_t bucket;
   bool valid;
 };
-template <int K>
-__device__ inline void chain_issue_wave(const TableView& t, ChainKey* ck, uint64_t child, uint32_t c,
-                                        DirCache* dc, PendingLookup* p) {
-  const uint64_t P = child & t.pmask;
+__device__ inline uint32_t lane_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ inline uint64_t lane_u64(uint64_t v, uint32_t l) {
+  return ((uint64_t)lane_u32((uint32_t)(v >> 32), l) << 32) | lane_u32((uint32_t)v, l);
+}
+// ck <- key state of the group of child = x[1:] + c (P = child & pmask), from the key state of x's group
+__device__ inline void chain_key_step(const TableView& t, ChainKey* ck, uint64_t P, uint32_t c) {
   uint64_t R;
   uint32_t best = 0, bc = 0, bs = 0, bucket = 0;
   bool searched = false;
-  if (K != 0 && ck->valid) {
+  if (ck->valid) {
     R = (ck->R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
     if ((ck->best & SEL_POS) != 0) {
       const uint32_t f = (uint32_t)P & t.mmask;
@@ -507,28 +509,60 @@ __device__ inline void chain_issue_wave(const TableView& t, ChainKey* ck, uint64
     bucket = bucket_of(t, bc);
   }
   ck->R = R; ck->best = best; ck->bc = bc; ck->bs = bs; ck->bucket = bucket; ck->valid = true;
-  Key g;
-  finish_key(t, P, R, bc, bs, best & SEL_POS, &g);
-  g.bucket = bucket;
-  p->X = child;
-  p->g = g;
-#ifdef KM_DFS_STAMPS
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p->t_key)::"memory");
-#endif
-  if (bucket != dc->bucket) {
-    const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + bucket);
-    dc->bucket = bucket; dc->lo = d.lo; dc->hi = d.hi;
+}
+
+// ---- A bucket held in the wave's registers (k_dfs chain runs).  The k-mers of a chain share
+// their minimizer for ~w/2 steps, and with it the bucket: lane j keeps slot j of that bucket, so
+// that a lookup is one compare of the tag against all its slots — no hashing to a home pair, no
+// memory access, no latency — until the minimizer changes.  A key never leaves its bucket
+// (probing wraps inside it), so "some slot of the bucket holds the tag" is exactly the table's
+// own answer.  Buckets of more than 64 slots are not held (resident = false).
+constexpr uint32_t BUCKET_LANES_SETS = 4;          // slots per lane: buckets of up to 256 slots are held
+struct BucketLanes {
+  uint64_t tag[BUCKET_LANES_SETS], zw[BUCKET_LANES_SETS];   // lane j, set i: slot 64 i + j (tag = EMPTY past the end)
+  uint32_t bucket, S;    // wave-uniform
+  bool valid, resident;
+};
+__device__ inline void bucket_load_wave(const TableView& t, uint32_t bucket, BucketLanes* b, uint32_t* fetches) {
+  const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + bucket);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.lo);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.hi);
+  const uint32_t S = 2u * (hi - lo);
+  b->bucket = bucket; b->S = S; b->valid = true; b->resident = S <= 64u * BUCKET_LANES_SETS;
+  if (b->resident) {
+    const uint32_t lane = (uint32_t)lane_id();
+#pragma unroll
+    for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
+      b->tag[i] = EMPTY; b->zw[i] = 0;
+      if (64u * i < S) {                             // wave-uniform
+        if (64u * i + lane < S) {
+          const uint4 v = *reinterpret_cast<const uint4*>(t.slots + 2ull * lo + 64u * i + lane);
+          b->tag[i] = ((uint64_t)v.y << 32) | v.x;
+          b->zw[i] = ((uint64_t)v.w << 32) | v.z;
+        }
+      }
+    }
+    *fetches += S;
   }
-  p->S = bucket_slots(dc->lo, dc->hi);
-  p->base = t.slots + 2ull * dc->lo;
-  p->idx = home_slot(t, p->g, p->S);
-  const Slot* b0 = (p->S ? p->base : t.slots) + p->idx;
-  uint32_t lane_zero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-  const uint4* q = reinterpret_cast<const uint4*>(b0) + lane_zero;
-  p->a0 = q[0];
-  p->a1 = q[1];
-  p->valid = true;
+}
+// count words of the group `tag` in a resident bucket (0 if absent)
+__device__ inline uint64_t bucket_find_wave(const BucketLanes& b, uint64_t tag) {
+  uint64_t zw = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
+    if (64u * i < b.S) {
+      const unsigned long long hit = __ballot(b.tag[i] == tag);
+      if (hit) zw = lane_u64(b.zw[i], (uint32_t)__ffsll((long long)hit) - 1);
+    }
+  }
+  return zw;
+}
+// canonical tag of the group of the (k-1)-mer P (R = its reverse complement)
+__device__ inline uint64_t group_tag(const TableView& t, uint64_t P, uint64_t R, uint32_t* flip) {
+  const uint32_t ph = (uint32_t)(P >> 32), rh = (uint32_t)(R >> 32);
+  const bool fwd = !t.canonical || ph < rh || (ph == rh && (uint32_t)P <= (uint32_t)R);
+  *flip = fwd ? 0u : 1u;
+  return fwd ? (P << 1) : ((R << 1) | 1ull);
 }
 
 // Counts of the group requested in p as the two count words of its slot (four u16 in slot order),

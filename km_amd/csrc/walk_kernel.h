@@ -552,6 +552,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   if (__any((int)dup)) st = T_REPEAT;
 #ifdef KM_DFS_STAMPS
   uint32_t dfs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dfs_prev, dfs_t0, dfs_steps = 0;   // 32 bits: few SGPRs
+  uint32_t dfs_loads = 0, dfs_nonres = 0, dfs_maxS = 0;
   {
     unsigned long long t_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
@@ -634,16 +635,32 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             bool expanded = false;                         // (c4, mask) = a finished expansion of x
             ChainKey ck;
             ck.valid = false;
+            BucketLanes bl;
+            bl.valid = false; bl.resident = false; bl.bucket = 0; bl.S = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) { bl.tag[i] = EMPTY; bl.zw[i] = 0; }
             const uint32_t lane3 = lane & 3u;
             while (n < room) {
               const uint64_t child = ((x << 2) | c) & tab.kmask;
               // a child that sits in its home slot of the node set is (most likely) a rejoin:
               // stop here and let the general step decide.  Only a hint — misses are caught below.
               const uint64_t at_home = keys[set_home(child, cap)];
-              chain_issue_wave<K>(tab, &ck, child, c, &dcache, &pend);
+              // the child's group: its key state follows from the last one, its bucket is (mostly)
+              // the one the lanes already hold (device_common.h: BucketLanes)
+              const uint64_t P = child & tab.pmask;
+              chain_key_step(tab, &ck, P, c);
+              uint32_t flip;
+              const uint64_t tag = group_tag(tab, P, ck.R, &flip);
+              KM_DFS_STAMP(9);
+              if (!bl.valid || bl.bucket != ck.bucket) {
+                bucket_load_wave(tab, ck.bucket, &bl, &fetch_u);
 #ifdef KM_DFS_STAMPS
-              dfs_acc[9] += (uint32_t)pend.t_key - dfs_prev;
-              dfs_prev = (uint32_t)pend.t_key;
+                ++dfs_loads;
+                if (bl.S > dfs_maxS) dfs_maxS = bl.S;
+#endif
+              }
+#ifdef KM_DFS_STAMPS
+              if (!bl.resident) ++dfs_nonres;
 #endif
               KM_DFS_STAMP(3);
 #ifdef KM_DFS_STAMPS_CALIBRATE
@@ -655,19 +672,17 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               x = child;
               // ---- the expansion of child: counts as the slot's two count words when the home
               // pair settles the lookup and no count is escaped; the thresholds on four lanes
-              uint64_t zw;
-              uint32_t f_add = 0;
-              bool packed_ok = chain_counts_packed(pend, &zw, &f_add);
+              uint64_t zw = 0;
+              bool packed_ok = bl.resident;
+              if (packed_ok) zw = bucket_find_wave(bl, tag);
               uint32_t cl = 0, xm = 0;
-              const uint32_t flip3 = pend.g.flip ? 3u : 0u;
+              const uint32_t flip3 = flip ? 3u : 0u;
               if (packed_ok) {
                 cl = (uint32_t)(zw >> ((lane3 ^ flip3) << 4)) & 0xFFFFu;   // lane i < 4: count of child base i
                 packed_ok = (__ballot(cl == COUNT_ESCAPE) & 0xFull) == 0;
               }
               KM_DFS_STAMP(2);
               if (packed_ok) {
-                fetch_u += f_add;
-                pend.valid = false;
                 const uint32_t z = (uint32_t)zw, w = (uint32_t)(zw >> 32);
                 const uint64_t sum = (uint64_t)((z & 0xFFFFu) + (z >> 16) + (w & 0xFFFFu) + (w >> 16));
                 uint32_t T = a.thr_T;
@@ -685,10 +700,15 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 c4 = make_uint4((uint32_t)(zw >> ((0u ^ flip3) << 4)) & 0xFFFFu, (uint32_t)(zw >> ((1u ^ flip3) << 4)) & 0xFFFFu,
                                 (uint32_t)(zw >> ((2u ^ flip3) << 4)) & 0xFFFFu, (uint32_t)(zw >> ((3u ^ flip3) << 4)) & 0xFFFFu);
               } else {
-                c4 = children_finish_wave(tab, pend, &fetch_u);
-                pend.valid = false;
+                // a bucket too large for the lanes, or an escaped count: the general lookup
+                c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
                 xm = child_mask(c4, a.ratio, a.n_cutoff);
                 KM_DFS_STAMP(8);
+                if (xm != 0 && (xm & (xm - 1)) == 0) {
+                  c = (uint32_t)__ffs((int)xm) - 1;
+                  cnt = pick4(c4, c);
+                  continue;
+                }
               }
               mask = xm;
               expanded = true;
@@ -716,10 +736,13 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 if (found) st8 = state[slot];
               }
               bool stop = act && (slot < 0 || (found && (st8 == ST_NODE || st8 == ST_ONSTACK)));
-              for (uint32_t i = 0; i + 1 < n; ++i) {       // ... or repeats an earlier child of the run
-                const uint64_t ki = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(rkey >> 32), (int)i) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, (int)i);
-                stop = stop || (act && lane > i && rkey == ki);
+              // ... or repeats an earlier child of the run (a loop).  Every child of a run is a
+              // function of the one before it (its only kept child), so a run that repeats a
+              // k-mer is periodic from there on and its LAST k-mer occurs earlier as well: one
+              // comparison tells whether the pairwise search is needed at all.
+              if (__any((int)(lane + 1 < n && rkey == lane_u64(rkey, n - 1)))) {
+                for (uint32_t i = 0; i + 1 < n; ++i)
+                  stop = stop || (act && lane > i && rkey == lane_u64(rkey, i));
               }
               const unsigned long long stops = __ballot(stop);
               const uint32_t f = stops ? (uint32_t)__ffsll((long long)stops) - 1 : n;
@@ -881,6 +904,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     for (int q = 0; q < 8; ++q) o[q] = dfs_acc[q];
     o[8] = dfs_steps; o[9] = (uint32_t)tend - dfs_t0; o[10] = t; o[11] = probes_u;
     o[12] = dfs_acc[8]; o[13] = dfs_acc[9];
+    o[14] = (unsigned long long)dfs_loads | ((unsigned long long)dfs_nonres << 20) | ((unsigned long long)dfs_maxS << 40);
     o[15] = 0x6466735f7374616dull;                         // record marker
   }
 #endif

@@ -883,7 +883,8 @@ def test_cli_two_ranks_target_sharded(tmp_path):
     p = subprocess.run([sys.executable, "-m", "km_amd", "find_mutation"] + case["targets"] + [case["db"]],
                        cwd=HERE, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    out = [l for l in p.stdout.splitlines() if not l.startswith("#Elapsed time") and "peer ranks" not in l]   # gloo chatters on stdout
+    out = [l for l in p.stdout.splitlines()
+           if l.strip() and not l.startswith("#Elapsed time") and "peer ranks" not in l]   # gloo chatters on stdout
     assert out == case["lines"]
     # sample-sharded driver, two ranks
     mat = _load("sample_matrix.json")

@@ -51,6 +51,11 @@ for i in order[:5]:
     print("  target %5d: %7d ticks, %3d expansions (%5.0f ticks each), %4d probes, setup+tail %4.1f %%: " %
           (r[10], r[9], r[8], sec.sum() / max(1, r[8]), r[11], 100 * (1 - sec.sum() / r[9])) +
           ", ".join("%s %.0f%%" % (nm, 100 * v / sec.sum()) for nm, v in zip(names, sec) if v))
+extra = rec[:, 14]
+loads, nonres, maxS = extra & 0xFFFFF, (extra >> 20) & 0xFFFFF, extra >> 40
+print("bucket loads %d, chain lookups in a bucket too large for the lanes %d, largest bucket %d slots; "
+      "loads per wave p50 %d max %d" % (loads.sum(), nonres.sum(), maxS.max(), np.median(loads), loads.max()))
+print("largest-bucket histogram (per wave):", np.bincount(np.minimum(maxS // 32, 16)).tolist())
 sec = rec[:, SEC].astype(np.float64).sum(axis=0)
 print("all waves: %.0f ticks per expansion; setup+tail %.1f %% of wave time; " %
       (sec.sum() / rec[:, 8].sum(), 100 * (1 - sec.sum() / tot.sum())) +
