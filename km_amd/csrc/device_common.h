@@ -481,12 +481,19 @@ __device__ inline uint32_t lane_u32(uint32_t v, uint32_t l) { return (uint32_t)_
 __device__ inline uint64_t lane_u64(uint64_t v, uint32_t l) {
   return ((uint64_t)lane_u32((uint32_t)(v >> 32), l) << 32) | lane_u32((uint32_t)v, l);
 }
+// ck <- key state of the group of the (k-1)-mer P, from scratch
+__device__ inline void chain_key_init(const TableView& t, ChainKey* ck, uint64_t P) {
+  ck->R = revcomp(P, t.k - 1);
+  minimizer_wave(t, P, ck->R, &ck->best, &ck->bc, &ck->bs);
+  ck->bucket = bucket_of(t, ck->bc);
+  ck->valid = true;
+}
 // ck <- key state of the group of child = x[1:] + c (P = child & pmask), from the key state of x's group
 __device__ inline void chain_key_step(const TableView& t, ChainKey* ck, uint64_t P, uint32_t c) {
   uint64_t R;
   uint32_t best = 0, bc = 0, bs = 0, bucket = 0;
   bool searched = false;
-  if (ck->valid) {
+  {
     R = (ck->R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
     if ((ck->best & SEL_POS) != 0) {
       const uint32_t f = (uint32_t)P & t.mmask;
@@ -501,8 +508,6 @@ __device__ inline void chain_key_step(const TableView& t, ChainKey* ck, uint64_t
       }
       searched = true;
     }
-  } else {
-    R = revcomp(P, t.k - 1);
   }
   if (!searched) {
     minimizer_wave(t, P, R, &best, &bc, &bs);
@@ -547,22 +552,27 @@ __device__ inline void bucket_load_wave(const TableView& t, uint32_t bucket, Buc
 }
 // count words of the group `tag` in a resident bucket (0 if absent)
 __device__ inline uint64_t bucket_find_wave(const BucketLanes& b, uint64_t tag) {
-  uint64_t zw = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
-    if (64u * i < b.S) {
-      const unsigned long long hit = __ballot(b.tag[i] == tag);
-      if (hit) zw = lane_u64(b.zw[i], (uint32_t)__ffsll((long long)hit) - 1);
-    }
-  }
-  return zw;
+  static_assert(BUCKET_LANES_SETS == 4, "unrolled by hand");
+  unsigned long long hit = __ballot(b.tag[0] == tag);
+  if (hit) return lane_u64(b.zw[0], (uint32_t)__ffsll((long long)hit) - 1);
+  if (b.S <= 64u) return 0;
+  hit = __ballot(b.tag[1] == tag);
+  if (hit) return lane_u64(b.zw[1], (uint32_t)__ffsll((long long)hit) - 1);
+  if (b.S <= 128u) return 0;
+  hit = __ballot(b.tag[2] == tag);
+  if (hit) return lane_u64(b.zw[2], (uint32_t)__ffsll((long long)hit) - 1);
+  hit = __ballot(b.tag[3] == tag);
+  if (hit) return lane_u64(b.zw[3], (uint32_t)__ffsll((long long)hit) - 1);
+  return 0;
 }
 // canonical tag of the group of the (k-1)-mer P (R = its reverse complement)
 __device__ inline uint64_t group_tag(const TableView& t, uint64_t P, uint64_t R, uint32_t* flip) {
-  const uint32_t ph = (uint32_t)(P >> 32), rh = (uint32_t)(R >> 32);
-  const bool fwd = !t.canonical || ph < rh || (ph == rh && (uint32_t)P <= (uint32_t)R);
-  *flip = fwd ? 0u : 1u;
-  return fwd ? (P << 1) : ((R << 1) | 1ull);
+  // (selects by arithmetic: as branches these cost the one wave that walks a chain more than the work)
+  uint64_t diff;
+  const bool rev = __builtin_usubl_overflow(R, P, &diff) && t.canonical;   // R < P
+  const uint64_t m = 0ull - (uint64_t)rev;
+  *flip = (uint32_t)rev;
+  return (((R << 1) | 1ull) & m) | ((P << 1) & ~m);
 }
 
 // Counts of the group requested in p as the two count words of its slot (four u16 in slot order),

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             uint32_t cnt = pick4(c4, c);
             bool expanded = false;                         // (c4, mask) = a finished expansion of x
             ChainKey ck;
-            ck.valid = false;
+            chain_key_init(tab, &ck, x & tab.pmask);       // of x's own group: every child's follows from it
             BucketLanes bl;
             bl.valid = false; bl.resident = false; bl.bucket = 0; bl.S = 0;
 #pragma unroll
