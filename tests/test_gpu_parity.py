@@ -455,6 +455,71 @@ def test_full_batch_against_c_oracle():
     assert n_multi > 600
 
 
+def _db_from_reads(reads, k, cov):
+    """Canonical k-mer records of a list of (sequence, coverage) reads (coverages add up)."""
+    acc = {}
+    for seq, c in reads:
+        keys = km.canonical(km.sliding_kmers(km.encode(seq), k), k)
+        for key in keys.tolist():
+            acc[key] = acc.get(key, 0) + c
+    keys = np.array(sorted(acc), dtype=np.uint64)
+    counts = np.array([acc[x] for x in keys.tolist()], dtype=np.uint32)
+    return keys, counts
+
+
+@pytest.mark.parametrize("k", [11, 21, 31, 32])
+def test_chain_runs_loops_budgets_and_escaped_counts(k):
+    """The walk books a chain of single children as one run (walk_kernel.h): chains that close a
+    loop on themselves (tandem repeats whose reads never leave the repeat), chains cut by the
+    stack budget at every possible length, chains through counts >= 65535 and a chain that
+    rejoins the target — against the Python oracle, node for node and probe for probe."""
+    rng = np.random.default_rng(4200 + k)
+
+    def rand_seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    left, right, mid = rand_seq(k + 9), rand_seq(k + 9), rand_seq(k + 25)
+    unit3, unit5 = "CAG", "ACGTT"
+    target_a = left + mid + right                                   # plain target
+    ins = rand_seq(70)                                              # a 70-nt insertion: one chain of 70 + k - 1 nodes
+    reads = [(target_a, 60), (left + mid[:12] + ins + mid[12:] + right, 40)]
+    # reads that enter a tandem repeat from the target and never leave it: the walk circles it
+    target_b = rand_seq(k + 5) + unit3 * 2 + rand_seq(k + 7)
+    cut = k + 5 + 6
+    reads += [(target_b, 50), (target_b[:cut] + unit3 * (k + 4), 30)]
+    target_c = rand_seq(k + 6) + unit5 + rand_seq(k + 8)
+    cut_c = k + 6 + 5
+    reads += [(target_c, 50), (target_c[:cut_c] + unit5 * (k // 2 + 6), 25)]
+    # a high-coverage variant: every count on its chain is stored escaped
+    target_d = rand_seq(3 * k)
+    var_d = target_d[:k + 4] + ("A" if target_d[k + 4] != "A" else "C") + target_d[k + 5:]
+    reads += [(target_d, 70_000), (var_d, 90_000)]
+    keys, counts = _db_from_reads(reads, k, None)
+    db = kmlib.Database.from_records(keys, counts, k).upload(0)
+    assert (db.query(keys) == counts).all()
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": k, "canonical": True, "keys": keys, "counts": counts})
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    targets = [("plain", target_a), ("cag", target_b), ("acgtt", target_c), ("deep", target_d)]
+    try:
+        for name, seq in targets:                                   # the oracle refuses targets with a repeated k-mer
+            ko.analyse_target(seq, name, cpu)
+    except ValueError:
+        pytest.skip("random flank produced a repeated k-mer")
+    got = _compare_with_oracle(jf, cpu, targets)
+    assert len(got[0].kmers) >= len(target_a) - k + 1 + 70          # the insertion chain was walked
+    assert len(got[1].kmers) > len(target_b) - k + 1                # ... and the repeat entered
+    # the stack budget cuts the chain at every length from 1 to past its end; the break and node
+    # budgets are exercised along the way
+    for steps in list(range(1, 12)) + [40, 63, 64, 65, 66, 70 + k - 2, 70 + k - 1, 70 + k, 127, 128, 129]:
+        _compare_with_oracle(jf, cpu, targets, steps=steps)
+    n_ref_a = len(target_a) - k + 1
+    for nodes in (n_ref_a, n_ref_a + 1, n_ref_a + 30, n_ref_a + 70 + k - 2, n_ref_a + 70 + k - 1):
+        _compare_with_oracle(jf, cpu, targets[:1], nodes=nodes)
+    for branchs in (0, 1, 2):
+        _compare_with_oracle(jf, cpu, targets, branchs=branchs)
+    db.close()
+
+
 @pytest.mark.parametrize("k,canonical", [(32, True), (15, True), (31, False), (24, False)])
 def test_other_k_and_non_canonical_databases(k, canonical):
     """k = 32 fills the whole uint64 key; non-canonical databases are looked up as stored
