@@ -271,6 +271,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
                     "multi-rank flow, records broadcast through host memory)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--serial", action="store_true",
+                    help="KM_RUN_SERIAL on every run: each kernel alone on the GPU, one stream (the command "
+                         "behind profiles/*kernel_stats.csv: rocprofv3 then times the kernels as the roofline "
+                         "section does)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
@@ -378,7 +382,7 @@ def main():
         bq.set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
         batches.append(bq)
     torch.cuda.synchronize()
-    stages = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH)
+    stages = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH) | (kmlib.KM_RUN_SERIAL if args.serial else 0)
     if args.hipgraph:
         stages |= kmlib.KM_RUN_HIPGRAPH
     deliver_full = stages | kmlib.KM_RUN_DELIVER
@@ -463,7 +467,11 @@ def main():
             tm.append(batch.timings())
         return [float(x) for x in np.mean(np.array(tm), axis=0)]
 
-    walk_avg, graph_avg, _tot, seed_avg, pack_avg, dfs_avg, outk_avg, d2h_avg = event_times(deliver)
+    # every kernel alone on the GPU (KM_RUN_SERIAL: the pass over the unflagged targets follows k_dfs
+    # instead of running beside it) — a kernel's own duration, what rocprofv3 reports for
+    # `bench.py --serial`; and the same step as the pipeline launches it (k_graph_pure beside k_dfs)
+    walk_avg, graph_avg, _tot, seed_avg, pack_avg, dfs_avg, outk_avg, d2h_avg = event_times(deliver | kmlib.KM_RUN_SERIAL)
+    ovl = event_times(deliver)
     outk_full, d2h_full = event_times(deliver_full)[6:8]
 
     # ---- result fetch through the copying API (numpy arrays, node k-mers rebuilt), for scale
@@ -673,7 +681,11 @@ def main():
             "targets_in_large_tier": int(sizes[0].n_big_tier), "targets_flagged": int(sizes[0].n_flagged),
             "kernel_ms": {"walk": walk_avg, "k_pack": pack_avg, "k_seed": seed_avg, "k_dfs": dfs_avg,
                           "graph": graph_avg, "deliver_kernels": outk_avg, "d2h_copy": d2h_avg,
-                          "note": "one batch at a time, HIP events on the launch stream"},
+                          "note": "one batch at a time, every kernel alone on the GPU (KM_RUN_SERIAL), HIP events "
+                                  "on the launch stream; graph = k_graph_pure + k_graph",
+                          "as_pipelined": {"walk": ovl[0], "k_seed": ovl[3], "k_dfs": ovl[5], "graph": ovl[1],
+                                           "note": "the same with k_graph_pure beside k_dfs on the side stream, "
+                                                   "as every other number of this line runs it"}},
             "batches_in_flight": n_fl,
             "hipgraph_replay": bool(args.hipgraph),
             "ms_per_step_unpipelined": serial_ms,

@@ -1262,6 +1262,8 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   }
   if (stages & KM_STAGE_WALK) {
+    // the path-pool counters of the graph kernels (zeroed here, outside the timed walk stage)
+    HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
     if (b->timed) HIPCHK(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
     if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
@@ -1270,19 +1272,24 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     if (b->timed) HIPCHK(hipEventRecord(b->ev[4], st));
     // unflagged targets are final after k_seed: their pure-chain check runs on the side
     // stream while k_dfs (latency-bound, few waves) walks the flagged ones
-    HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
+    // KM_RUN_SERIAL: every kernel alone on the GPU, in one stream (k_graph_pure after k_dfs) — what
+    // per-kernel measurements want; the default overlaps k_graph_pure with k_dfs on the side stream
+    const bool serial = (stages & KM_RUN_SERIAL) != 0;
     hipEvent_t e_fork = capturing ? b->ev_cap_seed : b->ev_seed_done;
     hipEvent_t e_join = capturing ? b->ev_cap_pure : b->ev_pure_done;
-    HIPCHK(hipEventRecord(e_fork, st));
-    HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
     ga.use_need_full = 1;
-    launch_pure(b, b->side, ga);
-    HIPCHK(hipEventRecord(e_join, b->side));
+    if (!serial) {
+      HIPCHK(hipEventRecord(e_fork, st));
+      HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
+      launch_pure(b, b->side, ga);
+      HIPCHK(hipEventRecord(e_join, b->side));
+    }
     if (wa.tab.k == 31) hipLaunchKernelGGL((k_dfs<false, 31>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     else hipLaunchKernelGGL((k_dfs<false, 0>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
     HIPCHK(hipGetLastError());
     if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
-    HIPCHK(hipStreamWaitEvent(st, e_join, 0));
+    if (serial) launch_pure(b, st, ga);
+    else HIPCHK(hipStreamWaitEvent(st, e_join, 0));
     launch_graph(b, st, ga);
     HIPCHK(hipGetLastError());
     graph_launched = true;

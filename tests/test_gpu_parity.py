@@ -701,6 +701,26 @@ def test_delivery_view_equals_fetch():
     assert (np.asarray(w["node_count"]) == v["node_count"]).all() and int(w["path_off"][-1]) == 0
 
 
+def test_serial_measurement_flag_changes_nothing():
+    """KM_RUN_SERIAL only moves k_graph_pure from the side stream behind k_dfs."""
+    case = synth.make_case(n_targets=300, length=300, n_keys=60_000, seed=99, variant_frac=0.4)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    b = kmlib.Batch(db, max_targets=300, max_total_bases=300 * 300)
+    b.set_targets([km.decode(r) for r in case["targets"]])
+    flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    b.run(flags)
+    r0 = b.fetch()
+    b.run(flags | kmlib.KM_RUN_SERIAL | kmlib.KM_RUN_TIMED)
+    r1 = b.fetch()
+    assert sorted(r0) == sorted(r1)
+    for key in r0:
+        assert np.array_equal(r0[key], r1[key]), key
+    tm = b.timings()
+    assert tm[5] > 0 and tm[1] > 0
+    b.close()
+    db.close()
+
+
 def test_long_targets_take_the_large_tier_one_by_one():
     """A batch mixing 2-3 kb targets (beyond the LDS-resident tier) with ordinary ones: the long
     ones — flagged or not — go through the large tier individually, the rest stay on the fast

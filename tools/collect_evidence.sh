@@ -7,7 +7,10 @@ out=gpurun_out/${1:-r02}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 -c "import __graft_entry__ as g; g.build()" || exit 1
-B="python3 bench.py --steps 20 --warmup 4 --no-cpu --only-step --check 0 --inflight 1 --cache /tmp/kmc"
+# --serial: each kernel alone on the GPU (KM_RUN_SERIAL), so that a kernel's duration in the trace is
+# its own; with k_graph_pure beside k_dfs the profiler stretches both (147 / 97 us against 97 / - by
+# HIP events without it).  The PMC passes serialise the kernels anyway.
+B="python3 bench.py --steps 20 --warmup 4 --no-cpu --only-step --check 0 --inflight 1 --serial --cache /tmp/kmc"
 echo "[1/6] kernel trace"; rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- $B > $out/trace.json 2> $out/trace.err || exit 1
 echo "[2/6] pmc reads"; rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_32B_sum -d $out/pmc1 --output-format csv -- $B > $out/pmc1.json 2> $out/pmc1.err || exit 1
 echo "[3/6] pmc writes / L2"; rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $out/pmc2 --output-format csv -- $B > $out/pmc2.json 2> $out/pmc2.err || exit 1
