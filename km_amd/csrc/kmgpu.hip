@@ -1212,6 +1212,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   const bool want_deliver = (stages & KM_RUN_DELIVER) != 0;
   const bool want_lean = (stages & KM_DELIVER_LEAN) != 0;
   const bool want_timed = (stages & KM_RUN_TIMED) != 0;
+  const bool serial = (stages & KM_RUN_SERIAL) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
   b->deliver_pending = b->result_ready = false;
   b->timed_deliver = false;
@@ -1227,7 +1228,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     int rc = restore_layout(b, st);
     if (rc != KM_OK) return rc;
   }
-  if (want_graph && b->gexec && b->graph_stages == stages && b->graph_stream == st) {
+  if (want_graph && !serial && b->gexec && b->graph_stages == stages && b->graph_stream == st) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
     b->ran_walk = true;
     b->ran_graph = true;
@@ -1274,7 +1275,6 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     // stream while k_dfs (latency-bound, few waves) walks the flagged ones
     // KM_RUN_SERIAL: every kernel alone on the GPU, in one stream (k_graph_pure after k_dfs) — what
     // per-kernel measurements want; the default overlaps k_graph_pure with k_dfs on the side stream
-    const bool serial = (stages & KM_RUN_SERIAL) != 0;
     hipEvent_t e_fork = capturing ? b->ev_cap_seed : b->ev_seed_done;
     hipEvent_t e_join = capturing ? b->ev_cap_pure : b->ev_pure_done;
     ga.use_need_full = 1;
