@@ -1266,7 +1266,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     // the path-pool counters of the graph kernels (zeroed here, outside the timed walk stage)
     HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
     if (b->timed) HIPCHK(hipEventRecord(b->ev[0], st));
-    hipLaunchKernelGGL(k_pack, dim3(b->n_targets), dim3(64), 0, st, wa);
+    hipLaunchKernelGGL(k_pack, dim3((b->n_targets + PACK_WAVES - 1) / PACK_WAVES), dim3(64 * PACK_WAVES), 0, st, wa);
     if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
       launch_seed(b->n_items, st, wa);

@@ -195,9 +195,11 @@ __device__ inline int set_find(const uint64_t* keys, uint32_t cap, uint64_t key,
 // ---------------------------------------------------------------------------- k_pack
 // ASCII bases -> 2-bit words (32 bases per uint64_t, first base most significant),
 // one extra zero word per target; per-target initial state.
-__global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
-  const uint32_t t = blockIdx.x;
+constexpr uint32_t PACK_WAVES = 4;      // targets per k_pack block (one wave each): 4x fewer, fatter blocks
+__global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
+  const uint32_t t = blockIdx.x * PACK_WAVES + (threadIdx.x >> 6);
   const uint32_t lane = (uint32_t)lane_id();
+  if (t >= a.n_targets) return;          // whole waves only; nothing below synchronises across waves
   const uint64_t off = a.toff[t];
   const uint64_t L = a.toff[t + 1] - off;
   const uint64_t wo = a.woff[t];
@@ -234,7 +236,10 @@ __global__ __launch_bounds__(64) void k_pack(WalkArgs a) {
   if (n_ref == 0) st = T_EMPTY;
   else if (any_bad) st = T_BAD_BASE;
   else if (a.max_stack > 0 && n_ref > a.max_node) st = T_NODE_LIMIT;  // first __extend call exits
-  __syncthreads();                                   // packed words of this target are visible
+  // the packed words of this target (written by other lanes of this wave) are visible
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   {
     const uint32_t n_it = (n_ref + SEED_BLOCK - 1) / SEED_BLOCK;
     const uint64_t nbase = a.node_base[t];
