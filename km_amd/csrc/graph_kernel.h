@@ -70,6 +70,12 @@ struct GraphArgs {
   uint32_t* need_full;       // k_graph_pure -> k_graph: target needs the general algorithm
   uint32_t use_need_full;    // k_graph: skip targets k_graph_pure already answered
   uint32_t hcap_pure;        // k_graph_pure: fingerprint slots (multiple of 64)
+  // Work list of k_graph (LDS tier): the flagged targets (k_seed's list, work_n[0] of them) followed
+  // by the unflagged ones k_graph_pure could not answer (appended there, work_n[1]; few).  Block b
+  // of k_graph takes entry b.  Null when every target goes to k_graph anyway (duplicate check
+  // only, ablations): block b then takes target b.
+  uint32_t* work_list;
+  uint32_t* work_n;
   // outputs
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   if (h_tflag) return;                         // k_graph handles it once k_dfs is done
   const uint32_t hcap = a.hcap_pure;
   if ((uint64_t)2 * (n_ref + 2) > (uint64_t)hcap || (a.dbg != 0 && !(a.dbg & 0x80u))) {
-    if (tid == 0) a.need_full[t] = 1;
+    if (tid == 0) { a.need_full[t] = 1; if (a.work_list) a.work_list[a.work_n[0] + atomicAdd(&a.work_n[1], 1u)] = t; }
     return;
   }
   const uint32_t* ncnt = a.node_cnt + nb;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t nwords = (n_ref + (uint32_t)a.k - 1 + 31) >> 5;
   uint64_t* words = reinterpret_cast<uint64_t*>(smem + (uint64_t)hcap * 4);
   if (nwords + 1 > a.words_cap) {
-    if (tid == 0) a.need_full[t] = 1;
+    if (tid == 0) { a.need_full[t] = 1; if (a.work_list) a.work_list[a.work_n[0] + atomicAdd(&a.work_n[1], 1u)] = t; }
     return;
   }
   {
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     }
   }
   if (__any((int)not_pure)) {
-    if (tid == 0) a.need_full[t] = 1;
+    if (tid == 0) { a.need_full[t] = 1; if (a.work_list) a.work_list[a.work_n[0] + atomicAdd(&a.work_n[1], 1u)] = t; }
     return;
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -239,8 +245,20 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   }
 }
 
+// Direct mode (large tier, a.tids given): block b works on target tids[b].  LDS tier: block b
+// works on entry b of the work list (GraphArgs::work_list) — the blocks that have something to do
+// are the first ones of the grid and are dispatched together; the others leave after one load
+// instead of being scattered among them, each holding 26 KB of LDS while it reads its headers.
 template <bool BIG, int K>
 __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
+  uint32_t t_;
+  if (BIG || a0.tids || !a0.work_list) {
+    t_ = a0.tids ? a0.tids[blockIdx.x] : blockIdx.x;
+  } else {
+    if (blockIdx.x >= a0.work_n[0] + a0.work_n[1]) return;
+    t_ = a0.work_list[blockIdx.x];
+  }
+  const uint32_t t = t_;
   GraphArgs a = a0;
   if constexpr (K != 0) {               // instantiated for one k: shifts and masks fold
     a.k = K;
@@ -255,7 +273,6 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t tid = threadIdx.x, NT = GRAPH_THREADS;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
-  const uint32_t t = a.tids ? a.tids[blockIdx.x] : blockIdx.x;
   // wave-local ordering for the sections only wave 0 executes
   auto wsync = [&]() {
     if constexpr (BIG) __threadfence_block();
@@ -294,6 +311,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     return;
   }
 
+  if (a.dbg == 8) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   unsigned char* wsb;
   if constexpr (BIG) wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
   else wsb = smem;
@@ -357,6 +375,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   for (uint32_t w = tid; w < n_removed_words; w += NT) removed[w] = 0;
   if (tid < 8) scal[tid] = 0;
   __syncthreads();
+  if (a.dbg == 9) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   uint32_t shared_prefix = 0;            // some other node has the same (k-1)-mer prefix
   uint32_t own_slot[MAXOWN];             // FUSED: 4 * slot + last base of this thread's nodes
   if constexpr (FUSED) {

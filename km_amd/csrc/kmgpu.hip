@@ -759,7 +759,7 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_fw_off.alloc((uint64_t)max_targets + 1));
   A(b->d_tflag.alloc(max_targets));
   A(b->d_flagged.alloc(max_targets));
-  A(b->d_nflagged.alloc(1));
+  A(b->d_nflagged.alloc(2));
   A(b->d_dfs_probes.alloc(max_targets));
   A(b->d_node_base.alloc(max_targets));
   A(b->d_node_cap.alloc(max_targets));
@@ -1000,6 +1000,8 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.kmask = mask_bits(b->db->k);
   g.pmask = mask_bits(b->db->k - 1);
   g.tids = nullptr;
+  g.work_list = b->d_flagged.p;
+  g.work_n = b->d_nflagged.p;
   g.n_targets = b->n_targets;
   g.node_kmer = b->d_node_kmer.p;
   g.node_cnt = b->d_node_cnt.p;
@@ -1036,6 +1038,7 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   const char* dbg = getenv("KM_DEBUG_FLAGS");
   g.dbg = dbg ? ((uint32_t)strtoul(dbg, nullptr, 0) >> 8) : 0;
   if (b->graph_mode == 1) g.dbg = 1;       // duplicate check only
+  if (g.dbg && !(g.dbg & 0x80u)) g.work_list = nullptr;   // every target goes through k_graph: no list
 }
 
 // ---- fast-tier geometry.  The LDS-resident kernels are sized for the longest target of the
@@ -1107,6 +1110,7 @@ static void launch_graph(km_batch* b, hipStream_t st, const GraphArgs& ga) {
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
   b->ga.use_need_full = 1;
+  HIPCHK(hipMemsetAsync(b->d_nflagged.p + 1, 0, sizeof(uint32_t), st));   // k_graph_pure appends its hand-overs again
   launch_pure(b, st, b->ga);
   launch_graph(b, st, b->ga);
   HIPCHK(hipGetLastError());

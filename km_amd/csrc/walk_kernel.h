@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
     a.dfs_probes[t] = 0;
     a.fetches[t] = 0;
     a.tflag[t] = 0;
-    if (t == 0) *a.n_flagged = 0;
+    if (t == 0) { a.n_flagged[0] = 0; a.n_flagged[1] = 0; }      // [1]: targets k_graph_pure hands to k_graph
   }
 }
 

@@ -19,10 +19,10 @@ b = kmlib.Batch(db, max_targets=T, max_total_bases=T * L)
 b.set_targets_packed(blob, offs)
 st = kmlib.stream_create(0)
 flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_TIMED
-names = {0: "full", 1: "1 prefix table + dup check", 2: "2 adjacency", 3: "2b links + dist init", 4: "3 dijkstra",
+names = {0: "full", 8: "0 launch + headers", 9: "1a LDS fill", 1: "1 prefix table + dup check", 2: "2 adjacency", 3: "2b links + dist init", 4: "3 dijkstra",
          5: "4 prev arrays", 6: "5 strip ref edges", 7: "6 candidates"}
 base = int(os.environ.get("KM_BASE_FLAGS", "0"), 0)      # walk-kernel ablation bits (low byte)
-stages = (0, 1, 2, 3, 4, 5, 6, 7) if not os.environ.get("ONLY_FULL") else (0,)
+stages = (0, 8, 9, 1, 2, 3, 4, 5, 6, 7) if not os.environ.get("ONLY_FULL") else (0,)
 for n in stages:
     os.environ["KM_DEBUG_FLAGS"] = hex((((0x80 | n) << 8) if n else 0) | base)
     tm = []
