@@ -271,6 +271,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
                     "multi-rank flow, records broadcast through host memory)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--py-loop", action="store_true",
+                    help="run the pipelined steps from a Python loop (wait_result + run per step) instead of "
+                         "km_batch_pump")
     ap.add_argument("--serial", action="store_true",
                     help="KM_RUN_SERIAL on every run: each kernel alone on the GPU, one stream (the command "
                          "behind profiles/*kernel_stats.csv: rocprofv3 then times the kernels as the roofline "
@@ -392,7 +395,14 @@ def main():
 
     def pipeline(n_steps, flags, wait):
         """n_steps steps round-robin over the workspaces; before a workspace is reused (and at
-        the end) its previous delivery is awaited, i.e. its results are in pinned host memory."""
+        the end) its previous delivery is awaited, i.e. its results are in pinned host memory.
+        The loop itself runs inside the library (km_batch_pump) unless --py-loop: with the
+        interpreter between a wait and the next launch a launch costs ~200 us of host time
+        instead of ~50 (tools/launch_cost.py) and the GPU runs dry."""
+        if wait and not args.py_loop:
+            kmlib.pump(batches, tstreams, n_steps, flags)
+            torch.cuda.synchronize()
+            return
         for i in range(n_steps):
             q = i % n_fl
             if wait and i >= n_fl:
@@ -441,6 +451,13 @@ def main():
     pipeline(n_fl, deliver, True)
     dt = timed(deliver, True)
     views, out_bytes = delivered_bytes()
+    # the same timed region driven from the interpreter (wait_result + run per step), for the record
+    dt_py = None
+    if not args.py_loop:
+        args.py_loop = True
+        pipeline(n_fl, deliver, True)
+        dt_py = timed(deliver, True)
+        args.py_loop = False
     check = None
     if rank == 0 and args.check > 0 and not args.walk_only:
         check = oracle_check(case, views, set_ids, T, args.check)
@@ -686,6 +703,9 @@ def main():
                           "as_pipelined": {"walk": ovl[0], "k_seed": ovl[3], "k_dfs": ovl[5], "graph": ovl[1],
                                            "note": "the same with k_graph_pure beside k_dfs on the side stream, "
                                                    "as every other number of this line runs it"}},
+            "host_loop": ("python (wait_result + run per step)" if args.py_loop else
+                          "km_batch_pump: the round-robin loop over the batches in flight runs inside the library"),
+            "ms_per_step_python_loop": (dt_py / args.steps * 1e3) if dt_py else None,
             "batches_in_flight": n_fl,
             "hipgraph_replay": bool(args.hipgraph),
             "ms_per_step_unpipelined": serial_ms,

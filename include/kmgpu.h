@@ -226,6 +226,11 @@ int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
  * Either output may be NULL.  This is what `km find_mutation` needs per target
  * (km/tools/find_mutation.py:49-58) and what km_report_rows consumes. */
 int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes);
+/* `steps` runs over `n` batches in flight, round robin (batch i % n on streams[i % n]): before a
+ * batch is run again its previous delivery is awaited, at the end every batch's.  The loop of a
+ * pipelined consumer (km/tools/find_mutation.py:47-58 over successive batches) without an
+ * interpreter between the launches. */
+int km_batch_pump(km_batch_t* const* batches, void* const* streams, int n, int steps, int stages);
 /* Durations (ms) of the last run (it must have carried KM_RUN_TIMED; zeros otherwise) measured
  * with HIP events on the launch stream:
  * [0] walk stage (k_pack + k_seed + k_dfs), [1] graph stage, [2] walk + graph,

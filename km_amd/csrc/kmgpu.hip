@@ -1,6 +1,7 @@
 // kmgpu.hip — libkmgpu.so: C-ABI (include/kmgpu.h) over the HIP kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -1126,6 +1127,7 @@ static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
 // Compaction kernels + ONE asynchronous copy of region A and the expected part of the tail into
 // the pinned twin; km_batch_result() waits for ev_out and fetches what the guess left behind.
 static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
+  const double h_in = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
   const uint32_t n = b->n_targets;
   b->lean = lean;
   const OutLayout L = out_layout(n);
@@ -1173,20 +1175,26 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.tail = dst + L.a_bytes;
   oa.tail_cap = b->out_cap - L.a_bytes;
   static const int dbg_deliver = getenv("KM_DEBUG_DELIVER") ? atoi(getenv("KM_DEBUG_DELIVER")) : 0;   // timing ablations only
+  static const bool host_trace = getenv("KM_TRACE_HOST") != nullptr;   // diagnostics: host time of the calls below
+  auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double h0 = host_trace ? now_us() : 0;
   if (!(dbg_deliver & 2)) {
     hipLaunchKernelGGL(k_out_scan, dim3((n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS), dim3(OUT_SCAN_THREADS), 0, st, oa);
     hipLaunchKernelGGL(k_out_pack, dim3(n), dim3(64), 0, st, oa);
   }
   HIPCHK(hipGetLastError());
+  const double h1 = host_trace ? now_us() : 0;
   if (b->timed) HIPCHK(hipEventRecord(b->ev[5], st));
   uint64_t guess = std::min<uint64_t>(oa.tail_cap, b->tail_guess);
   if (zero_copy) guess = oa.tail_cap;            // everything is already where it belongs
   else if (!(dbg_deliver & 1)) {
     HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, L.a_bytes + guess, hipMemcpyDeviceToHost, st));
   }
+  const double h2 = host_trace ? now_us() : 0;
   if (b->timed) HIPCHK(hipEventRecord(b->ev[6], st));
   b->timed_deliver = b->timed;
   HIPCHK(hipEventRecord(b->ev_out, st));
+  if (host_trace) fprintf(stderr, "[km host] deliver: kernels %.1f us, memcpyAsync %.1f us, event %.1f us, whole %.1f\n", h1 - h0, h2 - h1, now_us() - h2, now_us() - h_in);
   b->copied_tail = guess;
   b->deliver_pending = true;
   return KM_OK;
@@ -1207,8 +1215,14 @@ static int restore_layout(km_batch* b, hipStream_t st) {
   return KM_OK;
 }
 
+static double host_now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   if (!b) return fail(KM_E_ARG, "null argument");
+  static const bool host_trace = getenv("KM_TRACE_HOST") != nullptr;   // diagnostics: host time of the sections
+  double ht[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ht[0] = host_trace ? host_now_us() : 0;
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = (hipStream_t)stream;
   b->last_stream = st;
@@ -1232,6 +1246,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     int rc = restore_layout(b, st);
     if (rc != KM_OK) return rc;
   }
+  ht[1] = host_trace ? host_now_us() : 0;
   if (want_graph && !serial && b->gexec && b->graph_stages == stages && b->graph_stream == st) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
     b->ran_walk = true;
@@ -1266,9 +1281,11 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     drop_graph(b);
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   }
+  ht[2] = host_trace ? host_now_us() : 0;
   if (stages & KM_STAGE_WALK) {
     // the path-pool counters of the graph kernels (zeroed here, outside the timed walk stage)
     HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
+    ht[3] = host_trace ? host_now_us() : 0;
     if (b->timed) HIPCHK(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(k_pack, dim3((b->n_targets + PACK_WAVES - 1) / PACK_WAVES), dim3(64 * PACK_WAVES), 0, st, wa);
     if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
@@ -1323,7 +1340,14 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
   }
   b->synced = false;
-  return want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
+  if (host_trace) {
+    ht[4] = host_now_us();
+  }
+  const int rc_deliver = want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
+  if (host_trace)
+    fprintf(stderr, "[km host] run: setdevice+layout %.1f us, geometry %.1f, memset %.1f, launches %.1f, delivery %.1f, whole call %.1f\n",
+            ht[1] - ht[0], ht[2] - ht[1], ht[3] - ht[2], ht[4] - ht[3], host_now_us() - ht[4], host_now_us() - ht[0]);
+  return rc_deliver;
 }
 
 static int pull_status(km_batch* b, hipStream_t st) {
@@ -1541,6 +1565,22 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   return KM_OK;
 }
 
+// Wait for an event; KM_SPIN_US=n polls it for the first n microseconds instead of putting the
+// thread to sleep at once (default 0: on the boxes measured a polling consumer gained nothing,
+// 0.315 against 0.312 ms per delivered step).
+static hipError_t wait_event_hot(hipEvent_t ev) {
+  static const long spin_us = getenv("KM_SPIN_US") ? atol(getenv("KM_SPIN_US")) : 0;
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e != hipErrorNotReady) return e;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+  }
+  return hipEventSynchronize(ev);
+}
+
 // Results of the last run in the pinned delivery buffer (delivering now if the run did not).
 // `need_full`: a lean delivery (pending or ready) is replaced by a full one.
 static int finish_result(km_batch* b, bool need_full) {
@@ -1561,7 +1601,7 @@ static int finish_result(km_batch* b, bool need_full) {
   const OutLayout L = out_layout(b->n_targets);
   const unsigned long long* T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
   for (int attempt = 0;; ++attempt) {
-    HIPCHK(hipEventSynchronize(b->ev_out));
+    HIPCHK(wait_event_hot(b->ev_out));
     if (getenv("KM_DEBUG_DELIVER") && atoi(getenv("KM_DEBUG_DELIVER"))) {      // timing ablation: nothing valid arrived
       b->deliver_pending = false; b->result_ready = true;
       return KM_OK;
@@ -1642,6 +1682,29 @@ extern "C" int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_siz
   if (rc != KM_OK) return rc;
   if (view) view_of_result(b, view);
   if (sizes) sizes_of_result(b, sizes);
+  return KM_OK;
+}
+
+// `steps` runs over `n` batches in flight, round robin: before a batch is run again its last
+// delivery is awaited (km_batch_result), at the end every batch's.  The loop a pipelined consumer
+// writes, kept on the library's side of the ABI so that an interpreter between two launches does
+// not sit in the timed region (diagnostics / bench; tools/launch_cost.py).
+extern "C" int km_batch_pump(km_batch_t* const* bs, void* const* streams, int n, int steps, int stages) {
+  if (!bs || n <= 0 || steps < 0) return fail(KM_E_ARG, "bad argument");
+  const bool deliver = (stages & KM_RUN_DELIVER) != 0;
+  for (int i = 0; i < steps; ++i) {
+    km_batch_t* b = bs[i % n];
+    if (i >= n && deliver) {
+      int rc = finish_result(b, false);
+      if (rc != KM_OK) return rc;
+    }
+    int rc = km_batch_run(b, stages, streams ? streams[i % n] : nullptr);
+    if (rc != KM_OK) return rc;
+  }
+  for (int q = 0; q < std::min(n, steps); ++q) {
+    int rc = deliver ? finish_result(bs[q], false) : km_batch_sync(bs[q]);
+    if (rc != KM_OK) return rc;
+  }
   return KM_OK;
 }
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
-    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_debug_stamps",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_pump", "km_batch_debug_stamps",
     "km_report_rows", "km_report_free", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
@@ -137,6 +137,7 @@ def load():
         "km_batch_fetch": [vp, C.POINTER(BatchOut)],
         "km_batch_result": [vp, C.POINTER(BatchOut), C.POINTER(BatchSizes)],
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
+        "km_batch_pump": [C.POINTER(vp), C.POINTER(vp), i32, i32, i32],
         "km_batch_debug_stamps": [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)],
         "km_report_rows": [C.POINTER(ReportIn), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
                            C.POINTER(C.POINTER(C.c_int32))],
@@ -155,6 +156,15 @@ def load():
     lib.km_report_free.restype = None
     _lib = lib
     return lib
+
+
+def pump(batches, streams, steps, stages):
+    """km_batch_pump: `steps` runs over the batches in flight, round robin, deliveries awaited."""
+    lib = load()
+    n = len(batches)
+    bs = (C.c_void_p * n)(*[b._b for b in batches])
+    sts = (C.c_void_p * n)(*[C.c_void_p(s or 0) for s in streams])
+    check(lib.km_batch_pump(bs, sts, n, int(steps), int(stages)))
 
 
 def stream_create(device=0):

@@ -721,6 +721,38 @@ def test_serial_measurement_flag_changes_nothing():
     db.close()
 
 
+def test_pump_runs_the_batches_in_flight_like_a_hand_written_loop():
+    """km_batch_pump = the round-robin loop (await the batch's last delivery, run it again) inside
+    the library: every batch ends up with the results of a plain run."""
+    cases = [synth.make_case(n_targets=200, length=260, n_keys=50_000, seed=500 + i, variant_frac=0.5) for i in range(3)]
+    keys = np.unique(np.concatenate([c["keys"] for c in cases]))
+    # one table holding every case's k-mers (counts of the first case that has the key)
+    counts = np.zeros(keys.size, dtype=np.uint32)
+    for c in reversed(cases):
+        counts[np.searchsorted(keys, c["keys"])] = c["counts"]
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    batches, streams, want = [], [], []
+    for c in cases:
+        b = kmlib.Batch(db, max_targets=200, max_total_bases=200 * 260)
+        b.set_targets([km.decode(r) for r in c["targets"]])
+        b.run()
+        want.append(b.fetch())
+        batches.append(b)
+        streams.append(kmlib.stream_create(0))
+    flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_DELIVER
+    kmlib.pump(batches, streams, 7, flags)                       # 7 steps over 3 batches: uneven on purpose
+    for b, w in zip(batches, want):
+        got = b.fetch()
+        for key in w:
+            assert np.array_equal(got[key], w[key]), key
+    kmlib.pump(batches, streams, 4, kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH)   # without delivery: synced at the end
+    for b, w in zip(batches, want):
+        got = b.fetch()
+        assert np.array_equal(got["node_count"], w["node_count"]) and np.array_equal(got["path_min_cov"], w["path_min_cov"])
+        b.close()
+    db.close()
+
+
 def test_long_targets_take_the_large_tier_one_by_one():
     """A batch mixing 2-3 kb targets (beyond the LDS-resident tier) with ordinary ones: the long
     ones — flagged or not — go through the large tier individually, the rest stay on the fast
