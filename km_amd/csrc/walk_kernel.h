@@ -197,6 +197,11 @@ __device__ inline int set_find(const uint64_t* keys, uint32_t cap, uint64_t key,
 // one extra zero word per target; per-target initial state.
 constexpr uint32_t PACK_WAVES = 4;      // targets per k_pack block (one wave each): 4x fewer, fatter blocks
 __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
+  // a target's words are also kept in LDS (targets of up to PACK_LDS_WORDS * 32 bases): its item
+  // records are then built from there instead of reading the words back from memory
+  constexpr uint32_t PACK_LDS_WORDS = 192;
+  __shared__ uint64_t lds_words[PACK_WAVES][PACK_LDS_WORDS];
+  uint64_t* const mine = lds_words[threadIdx.x >> 6];
   const uint32_t t = blockIdx.x * PACK_WAVES + (threadIdx.x >> 6);
   const uint32_t lane = (uint32_t)lane_id();
   if (t >= a.n_targets) return;          // whole waves only; nothing below synchronises across waves
@@ -227,8 +232,12 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
     v |= __shfl_xor(v, 2);
     v |= __shfl_xor(v, 4);
     const uint32_t w = c * 8 + (lane >> 3);
-    if ((lane & 7) == 0 && w <= nwords) a.packed[wo + w] = v;
+    if ((lane & 7) == 0 && w <= nwords) {
+      a.packed[wo + w] = v;
+      if (w < PACK_LDS_WORDS) mine[w] = v;
+    }
   }
+  const bool in_lds = nwords < PACK_LDS_WORDS;
   const uint64_t fwo = a.fw_off[t];
   for (uint32_t w = lane; w < (n_ref + 31) / 32; w += 64) a.flagbits[fwo + w] = 0;
   const int any_bad = __any((int)bad);
@@ -237,9 +246,13 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
   else if (any_bad) st = T_BAD_BASE;
   else if (a.max_stack > 0 && n_ref > a.max_node) st = T_NODE_LIMIT;  // first __extend call exits
   // the packed words of this target (written by other lanes of this wave) are visible
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (in_lds) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: LDS runs its operations in order
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   {
     const uint32_t n_it = (n_ref + SEED_BLOCK - 1) / SEED_BLOCK;
     const uint64_t nbase = a.node_base[t];
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
       else if (f == 3) v = fwo;
       else {
         const uint32_t w = q * (SEED_BLOCK / 32) + (f - 4);
-        v = (w <= nwords) ? a.packed[wo + w] : 0ull;
+        v = (w <= nwords) ? (in_lds ? mine[w] : a.packed[wo + w]) : 0ull;
       }
       rec0[x] = v;
     }
