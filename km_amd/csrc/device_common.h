@@ -465,8 +465,8 @@ __device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCa
   p->a1 = q[1];
   p->valid = true;
 }
-// The same request for the next k-mer of a CHAIN (k_dfs walking a run of single children): the
-// key of child = x[1:] + c follows from the key state of x with a handful of scalar operations.
+// Key state along a CHAIN (k_dfs walking a run of single children): the key of
+// child = x[1:] + c follows from the key state of x with a handful of scalar operations.
 // The reverse complement shifts in one base; of the w windows only the last one is new, so the
 // minimizer is the old one moved one position to the left unless the new window beats it — or
 // the old one has just left the k-mer (one step in ~w), which costs the full wave-wide search.
@@ -475,7 +475,6 @@ struct ChainKey {
   uint32_t best;     // selection key of its minimizer (position in the low bits)
   uint32_t bc, bs;   // canonical m-mer and strand of the minimizer
   uint32_t bucket;
-  bool valid;
 };
 __device__ inline uint32_t lane_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ inline uint64_t lane_u64(uint64_t v, uint32_t l) {
@@ -486,34 +485,27 @@ __device__ inline void chain_key_init(const TableView& t, ChainKey* ck, uint64_t
   ck->R = revcomp(P, t.k - 1);
   minimizer_wave(t, P, ck->R, &ck->best, &ck->bc, &ck->bs);
   ck->bucket = bucket_of(t, ck->bc);
-  ck->valid = true;
 }
 // ck <- key state of the group of child = x[1:] + c (P = child & pmask), from the key state of x's group
 __device__ inline void chain_key_step(const TableView& t, ChainKey* ck, uint64_t P, uint32_t c) {
-  uint64_t R;
-  uint32_t best = 0, bc = 0, bs = 0, bucket = 0;
-  bool searched = false;
-  {
-    R = (ck->R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
-    if ((ck->best & SEL_POS) != 0) {
-      const uint32_t f = (uint32_t)P & t.mmask;
-      const uint32_t r = (uint32_t)(R >> (2 * (t.w - 1))) & t.mmask;
-      const uint32_t cn = f < r ? f : r;
-      const uint32_t seln = (mm_order(cn) & ~SEL_POS) | (uint32_t)(t.w - 1);
-      best = ck->best - 1u;                      // same window, one position further left
-      bc = ck->bc; bs = ck->bs; bucket = ck->bucket;
-      if (seln < best) {
-        best = seln; bc = cn; bs = f < r ? 0u : 1u;
-        bucket = bucket_of(t, bc);
-      }
-      searched = true;
+  const uint64_t R = (ck->R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
+  uint32_t best, bc, bs, bucket;
+  if ((ck->best & SEL_POS) != 0) {
+    const uint32_t f = (uint32_t)P & t.mmask;
+    const uint32_t r = (uint32_t)(R >> (2 * (t.w - 1))) & t.mmask;
+    const uint32_t cn = f < r ? f : r;
+    const uint32_t seln = (mm_order(cn) & ~SEL_POS) | (uint32_t)(t.w - 1);
+    best = ck->best - 1u;                        // same window, one position further left
+    bc = ck->bc; bs = ck->bs; bucket = ck->bucket;
+    if (seln < best) {
+      best = seln; bc = cn; bs = f < r ? 0u : 1u;
+      bucket = bucket_of(t, bc);
     }
-  }
-  if (!searched) {
+  } else {                                       // the minimizer was x's first window: search again
     minimizer_wave(t, P, R, &best, &bc, &bs);
     bucket = bucket_of(t, bc);
   }
-  ck->R = R; ck->best = best; ck->bc = bc; ck->bs = bs; ck->bucket = bucket; ck->valid = true;
+  ck->R = R; ck->best = best; ck->bc = bc; ck->bs = bs; ck->bucket = bucket;
 }
 
 // ---- A bucket held in the wave's registers (k_dfs chain runs).  The k-mers of a chain share
@@ -573,23 +565,6 @@ __device__ inline uint64_t group_tag(const TableView& t, uint64_t P, uint64_t R,
   const uint64_t m = 0ull - (uint64_t)rev;
   *flip = (uint32_t)rev;
   return (((R << 1) | 1ull) & m) | ((P << 1) & ~m);
-}
-
-// Counts of the group requested in p as the two count words of its slot (four u16 in slot order),
-// when the home pair settles it (the normal case).  false: the search has to go past the pair.
-__device__ inline uint64_t uniform64(uint32_t lo, uint32_t hi) {
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) |
-         (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-}
-__device__ inline bool chain_counts_packed(const PendingLookup& p, uint64_t* zw, uint32_t* fetches) {
-  if (p.S == 0) { *zw = 0; return true; }
-  const uint64_t t0 = uniform64(p.a0.x, p.a0.y);
-  if (t0 == p.g.tag) { *zw = uniform64(p.a0.z, p.a0.w); *fetches += 1; return true; }
-  if (t0 == EMPTY) { *zw = 0; *fetches += 1; return true; }
-  const uint64_t t1 = uniform64(p.a1.x, p.a1.y);
-  if (t1 == p.g.tag) { *zw = uniform64(p.a1.z, p.a1.w); *fetches += 2; return true; }
-  if (t1 == EMPTY) { *zw = 0; *fetches += 2; return true; }
-  return false;
 }
 
 __device__ inline uint4 uniform4(uint4 v) {

@@ -688,8 +688,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               if (lane == n) { rkey = child; rcnt = cnt; }
               ++n;
               x = child;
-              // ---- the expansion of child: counts as the slot's two count words when the home
-              // pair settles the lookup and no count is escaped; the thresholds on four lanes
+              // ---- the expansion of child: its group's two count words out of the bucket the
+              // lanes hold (no count escaped); the four thresholds are one compare on four lanes
               uint64_t zw = 0;
               bool packed_ok = bl.resident;
               if (packed_ok) zw = bucket_find_wave(bl, tag);
@@ -786,17 +786,17 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                   ++brk;
                   if (brk > a.max_break) mask = 0;
                 }
-                if (mask && depth + 1 <= a.max_stack && !(pend.valid && pend.X == (((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask)))
-                  children_issue_wave(tab, ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask, &dcache, &pend);
+                if (mask && depth + 1 <= a.max_stack) {        // the general step continues: request its lookup
+                  const uint64_t next = ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask;
+                  if (!(pend.valid && pend.X == next)) children_issue_wave(tab, next, &dcache, &pend);
+                }
               } else {
                 // child f is not new: its parent (child f - 1, or cur) is the top of the stack and
                 // has exactly this child left
-                const uint64_t kf = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(rkey >> 32), (int)f) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, (int)f);
-                const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)rcnt, (int)f);
+                const uint64_t kf = lane_u64(rkey, f);
+                const uint32_t cf = lane_u32(rcnt, f);
                 depth += f;
-                if (f) cur = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(rkey >> 32), (int)(f - 1)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, (int)(f - 1));
+                if (f) cur = lane_u64(rkey, f - 1);
                 c4 = make_uint4(cf, cf, cf, cf);
                 mask = 1u << (uint32_t)(kf & 3);
                 pend.valid = false;
