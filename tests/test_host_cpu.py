@@ -133,3 +133,23 @@ def test_native_reader_matches_oracle_reader(tmp_path):
     with pytest.raises(kmlib.KmError) as e:
         db.query(np.array([1], dtype=np.uint64))
     assert e.value.code == 7
+
+
+def test_threshold_shortcut_is_exact(tmp_path):
+    """The walk skips the float64 threshold for sums below a precomputed bound
+    (device_common.h: threshold_shortcut).  A host program built from the same header checks, over
+    fixed and random (ratio, cutoff) pairs, that every such sum has the threshold the float64
+    expression gives and that the bound is tight.  hipcc compiles it; nothing runs on a GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "threshold_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           "-o", exe, os.path.join(root, "tests", "host", "threshold_check.hip")],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout[-500:] + out.stderr[-500:]
+    assert int(out.stdout.split()[1]) > 3000
