@@ -553,6 +553,104 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   }
   __syncthreads();          // the prefix table is dead from here on: region A is reused
 
+  // ---- 2c. the one shape most variants have: the reference chain plus ONE forward bubble -------
+  // Nodes n_ref..m-1 (the walk's own) form a single chain a -> n_ref -> ... -> m-1 -> b with
+  // a < b on the reference, and there is no other irregular node.  Then (Graph.py:63-240 on this
+  // graph; oracle/km_oracle.py: graph_paths): the reference route between a and b costs
+  // (b - a) x 0.01 against (m - n_ref + 1) x 1.0 through the bubble, so — checked below with a
+  // margin far above float32 rounding — both shortest-path trees keep the reference edges into b
+  // and out of a; the chain walked from node 0 along after[] is the whole reference path, whose
+  // edges are all stripped but (0, 1); every bubble edge then yields the path
+  // 0..a, n_ref..m-1, b..n_ref-1 and the two surviving reference edges the reference path.
+  // Two paths, written straight away; steps 3-6 are skipped.
+  if constexpr (!BIG) {
+    if (a.dbg == 0 && m > n_ref && n_ref >= 2 && wave == 0) {
+      uint32_t z = 0;
+      if (lane < nbw) {
+        z = ~link[lane];
+        const uint32_t lo = lane * 32;
+        if (lo >= m) z = 0;
+        else if (m - lo < 32) z &= (1u << (m - lo)) - 1u;
+      }
+      const unsigned long long words = __ballot(z != 0);
+      uint32_t pos[4] = {0, 0, 0, 0}, np = 0;
+      bool ok = __popcll(words) <= 4;
+      for (unsigned long long r = words; ok && r; r &= r - 1) {
+        const uint32_t w = (uint32_t)__ffsll((long long)r) - 1;
+        for (uint32_t zz = lane_u32(z, w); zz; zz &= zz - 1) {
+          if (np == 4) { ok = false; break; }
+          pos[np++] = w * 32 + (uint32_t)__ffs((int)zz) - 1;
+        }
+      }
+      // clear link bits exactly at a, b - 1 (the same for an insertion), n_ref - 1 and m - 1
+      ok = ok && (np == 3 || np == 4) && pos[np - 1] == m - 1 && pos[np - 2] == n_ref - 1 && pos[np - 3] < n_ref - 1;
+      uint32_t fa = 0, fb = 0;
+      if (ok) {
+        fa = pos[0];
+        fb = pos[np - 3] + 1;
+        auto degree = [&](const idx_t* adj, uint32_t u, uint32_t want0, uint32_t want1) -> bool {
+          // the neighbours of u are exactly {want0, want1} (NIL = none)
+          uint32_t cnt = 0, hit0 = 0, hit1 = 0;
+          for (uint32_t c = 0; c < 4; ++c) {
+            const idx_t v = adj[4 * u + c];
+            if (v == NONE) continue;
+            ++cnt;
+            hit0 |= (uint32_t)v == want0;
+            hit1 |= (uint32_t)v == want1;
+          }
+          const uint32_t wanted = (want0 != NIL) + (want1 != NIL && want1 != want0);
+          return cnt == wanted && (want0 == NIL || hit0) && (want1 == NIL || hit1);
+        };
+        const uint32_t last = m - 1;
+        ok = fb <= n_ref - 1 && fa < fb;
+        ok = ok && degree(succ, fa, fa + 1, n_ref) && degree(pred, n_ref, fa, NIL);
+        ok = ok && degree(succ, last, fb, NIL) && degree(pred, fb, fb - 1, last);
+        if (fb - 1 != fa) ok = ok && degree(succ, fb - 1, fb, NIL) && degree(pred, fa + 1, fa, NIL);
+        ok = ok && degree(pred, 0, NIL, NIL) && degree(succ, n_ref - 1, NIL, NIL);
+        ok = ok && (uint64_t)(fb - fa) + 10 <= 100ull * (m - n_ref + 1);
+      }
+      if (lane == 0) { scal[2] = ok ? 1u : 0u; scal[3] = fa; scal[4] = fb; }
+    }
+    __syncthreads();
+    if (scal[2]) {
+      const uint32_t fa = scal[3], fb = scal[4];
+      // min coverage of the two paths: wave 0 the reference path, wave 1 the path through the bubble
+      if (wave < 2) {
+        uint32_t mc = 0xFFFFFFFFu;
+        auto over = [&](uint32_t lo, uint32_t hi) {            // [lo, hi)
+          for (uint32_t q = lo + lane; q < hi; q += 64) { const uint32_t c = ncnt[q]; mc = c < mc ? c : mc; }
+        };
+        if (wave == 0) over(0, n_ref);
+        else { over(0, fa + 1); over(n_ref, m); over(fb, n_ref); }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mc, o); mc = other < mc ? other : mc; }
+        if (lane == 0) scal[5 + wave] = mc;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long path_base = atomicAdd(&ctr[0], 2ull);
+        unsigned long long run_base = atomicAdd(&ctr[1], 4ull);
+        if (path_base + 2 > pg_paths || run_base + 4 > pg_runs) {
+          atomicExch(ovf, 1ull);               // pools exhausted: host enlarges them and reruns the stage
+          a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0;
+        } else {
+          path_base += (uint64_t)pg * pg_paths;
+          run_base += (uint64_t)pg * pg_runs;
+          a.r_start[run_base] = 0; a.r_len[run_base] = n_ref;
+          a.p_target[path_base] = t; a.p_runbase[path_base] = run_base; a.p_nruns[path_base] = 1;
+          a.p_len[path_base] = n_ref; a.p_mincov[path_base] = scal[5];
+          a.r_start[run_base + 1] = 0; a.r_len[run_base + 1] = fa + 1;
+          a.r_start[run_base + 2] = n_ref; a.r_len[run_base + 2] = m - n_ref;
+          a.r_start[run_base + 3] = fb; a.r_len[run_base + 3] = n_ref - fb;
+          a.p_target[path_base + 1] = t; a.p_runbase[path_base + 1] = run_base + 1; a.p_nruns[path_base + 1] = 3;
+          a.p_len[path_base + 1] = (fa + 1) + (m - n_ref) + (n_ref - fb); a.p_mincov[path_base + 1] = scal[6];
+          a.t_npaths[t] = 2; a.t_pathbase[t] = (uint32_t)path_base; a.t_nruns[t] = 4;
+        }
+        a.g_status[t] = T_OK;
+      }
+      return;
+    }
+  }
+
   // first index e >= u with link[e] clear (the end of the chain through u)
   auto chain_end = [&](uint32_t u) -> uint32_t {
     uint32_t w = u >> 5;
