@@ -520,6 +520,71 @@ def test_chain_runs_loops_budgets_and_escaped_counts(k):
     db.close()
 
 
+@pytest.mark.parametrize("k", [11, 15, 21, 31])
+def test_single_bubble_shortcut_and_its_limits(k):
+    """k_graph answers "reference chain + one forward bubble" in closed form (graph_kernel.h, 2c).
+    Shapes on both sides of every condition, against the Python oracle: substitution, insertion,
+    deletion (bubbles of each kind, also touching the first k-mers), a deletion so long that the
+    bubble is CHEAPER than the reference route between its ends (the shortest-path trees change:
+    general algorithm), a tandem duplication (the bubble runs backwards), two bubbles, a bubble plus
+    a dead-end branch."""
+    rng = np.random.default_rng(777 + k)
+
+    def rand_seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    def other(b):
+        return "ACGT"[("ACGT".index(b) + 1) % 4]
+
+    cases = []
+    p = 3 * k
+
+    def fresh():                                                     # every case its own target
+        return rand_seq(6 * k + 40)
+
+    base = fresh()
+    cases.append(("snv", base, [base[:p] + other(base[p]) + base[p + 1:]]))
+    base = fresh()
+    cases.append(("ins", base, [base[:p] + rand_seq(7) + base[p:]]))
+    base = fresh()
+    cases.append(("del", base, [base[:p] + base[p + 9:]]))
+    base = fresh()
+    q = k + 1                                                        # the bubble leaves from the first k-mers
+    cases.append(("early", base, [base[:q] + other(base[q]) + base[q + 1:]]))
+    base = fresh()
+    cases.append(("itd", base, [base[:p + 20] + base[p - 5:p + 20] + base[p + 20:]]))
+    base = fresh()
+    cases.append(("two", base, [base[:2 * k] + other(base[2 * k]) + base[2 * k + 1:],
+                                base[:4 * k + 10] + rand_seq(3) + base[4 * k + 10:]]))
+    base = fresh()
+    dead = base[:p] + other(base[p]) + rand_seq(k + 5)               # reads that leave and never come back
+    cases.append(("dead", base, [base[:p + 30] + other(base[p + 30]) + base[p + 31:], dead]))
+    # a deletion of more than 100 k - 10 k-mers for k = 11 and 15 (the bubble is the cheaper route)
+    long_t = rand_seq(1900 if k == 11 else (1750 if k == 15 else 1500))
+    cut_a, cut_b = 2 * k + 7, len(long_t) - 2 * k - 11
+    cases.append(("hugedel", long_t, [long_t[:cut_a] + long_t[cut_b:]]))
+    reads, targets = [], []
+    for name, target, variants in cases:
+        reads.append((target, 60))
+        reads += [(v, 35) for v in variants]
+        targets.append((name, target))
+    keys, counts = _db_from_reads(reads, k, None)
+    db = kmlib.Database.from_records(keys, counts, k).upload(0)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": k, "canonical": True, "keys": keys, "counts": counts})
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    try:
+        for name, seq in targets:
+            ko.analyse_target(seq, name, cpu)
+    except ValueError:
+        pytest.skip("random sequence produced a repeated k-mer")
+    got = _compare_with_oracle(jf, cpu, targets)
+    by_name = {name: g for (name, _), g in zip(targets, got)}
+    if k > 15:                                                       # (small k: chance overlaps add branches of their own)
+        assert len(by_name["snv"].paths) == 2 and len(by_name["ins"].paths) == 2 and len(by_name["del"].paths) == 2
+        assert len(by_name["two"].paths) == 3 and len(by_name["hugedel"].paths) == 2
+    db.close()
+
+
 @pytest.mark.parametrize("k,canonical", [(32, True), (15, True), (31, False), (24, False)])
 def test_other_k_and_non_canonical_databases(k, canonical):
     """k = 32 fills the whole uint64 key; non-canonical databases are looked up as stored
