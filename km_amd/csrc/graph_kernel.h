@@ -507,6 +507,103 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     }
   }
   if (a.dbg == 1) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
+  // the two paths of "reference chain + one forward bubble a -> n_ref .. m-1 -> b" (2c, 2c')
+  auto emit_bubble = [&](const uint32_t fa, const uint32_t fb) {
+    // min coverage of the two paths: wave 0 the reference path, wave 1 the path through the bubble
+    if (wave < 2) {
+      uint32_t mc = 0xFFFFFFFFu;
+      auto over = [&](uint32_t lo, uint32_t hi) {            // [lo, hi)
+        for (uint32_t q = lo + lane; q < hi; q += 64) { const uint32_t c = ncnt[q]; mc = c < mc ? c : mc; }
+      };
+      if (wave == 0) over(0, n_ref);
+      else { over(0, fa + 1); over(n_ref, m); over(fb, n_ref); }
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mc, o); mc = other < mc ? other : mc; }
+      if (lane == 0) scal[5 + wave] = mc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long path_base = atomicAdd(&ctr[0], 2ull);
+      unsigned long long run_base = atomicAdd(&ctr[1], 4ull);
+      if (path_base + 2 > pg_paths || run_base + 4 > pg_runs) {
+        atomicExch(ovf, 1ull);               // pools exhausted: host enlarges them and reruns the stage
+        a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0;
+      } else {
+        path_base += (uint64_t)pg * pg_paths;
+        run_base += (uint64_t)pg * pg_runs;
+        a.r_start[run_base] = 0; a.r_len[run_base] = n_ref;
+        a.p_target[path_base] = t; a.p_runbase[path_base] = run_base; a.p_nruns[path_base] = 1;
+        a.p_len[path_base] = n_ref; a.p_mincov[path_base] = scal[5];
+        a.r_start[run_base + 1] = 0; a.r_len[run_base + 1] = fa + 1;
+        a.r_start[run_base + 2] = n_ref; a.r_len[run_base + 2] = m - n_ref;
+        a.r_start[run_base + 3] = fb; a.r_len[run_base + 3] = n_ref - fb;
+        a.p_target[path_base + 1] = t; a.p_runbase[path_base + 1] = run_base + 1; a.p_nruns[path_base + 1] = 3;
+        a.p_len[path_base + 1] = (fa + 1) + (m - n_ref) + (n_ref - fb); a.p_mincov[path_base + 1] = scal[6];
+        a.t_npaths[t] = 2; a.t_pathbase[t] = (uint32_t)path_base; a.t_nruns[t] = 4;
+      }
+      a.g_status[t] = T_OK;
+    }
+  };
+
+  // ---- 2c'. the same shape read off the prefix table, before the adjacency is built ------------
+  // Edges are i -> j iff suffix(i) == prefix(j).  With (R1) the reference's (k-1)-mer prefixes
+  // pairwise distinct and the last reference suffix no node's prefix, (R2) the first walk node
+  // sharing its prefix with exactly one node, a reference node x in [1, n_ref-1] (both are children
+  // of a = x - 1), (R3) every later walk node e having prefix(e) == suffix(e-1) and a prefix of its
+  // own, and (R4) suffix(m-1) being the prefix of exactly one node, a reference node b > a — the
+  // graph has the reference edges j -> j+1, the chain a -> n_ref -> .. -> m-1 -> b and nothing
+  // else: any other edge would put a second node into a prefix slot that (R1)-(R4) say holds one.
+  // All of it is in the table already: how many nodes share a node's prefix is the number of
+  // occupied indices of its slot (kept in own_slot), and two lookups give (R1)'s and (R4)'s rest.
+  if constexpr (FUSED) {
+    if (a.dbg == 0 && m > n_ref && n_ref >= 2) {
+      uint32_t bad = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < MAXOWN; ++q) {
+        const uint32_t j = tid + q * NT;
+        if (j >= m) continue;
+        const uint32_t s4 = own_slot[q] & ~3u;
+        uint32_t cnt = 0, other = NIL;
+        for (uint32_t c = 0; c < 4; ++c) {
+          const idx_t v = pidx[s4 + c];
+          if (v == NONE) continue;
+          ++cnt;
+          if ((uint32_t)v != j) other = (uint32_t)v;
+        }
+        if (cnt > 2) bad = 1;
+        else if (cnt == 2) {
+          if (j == n_ref) { if (other >= 1 && other <= n_ref - 1) scal[3] = other - 1; else bad = 1; }
+          else if (j < n_ref) { if (other != n_ref) bad = 1; }
+          else bad = 1;                                           // a later walk node shares its prefix
+        } else if (j == n_ref) bad = 1;                           // the first walk node hangs off nothing
+        if (j > n_ref && (nk(j) >> 2) != (nk(j - 1) & a.pmask)) bad = 1;   // (R3)
+      }
+      if (tid == 0 || tid == 64) {
+        // (R1): suffix of the last reference k-mer absent; (R4): suffix of the last walk node -> b
+        const uint64_t S = nk(tid == 0 ? n_ref - 1 : m - 1) & a.pmask;
+        uint32_t s = set_home(S, hcap), hit = NIL;
+        for (uint32_t step = 0; step < hcap; ++step) {
+          const uint64_t kv = pkeys[s];
+          if (kv == S) { hit = s; break; }
+          if (kv == EMPTY) break;
+          if (++s == hcap) s = 0;
+        }
+        if (tid == 0) { if (hit != NIL) bad = 1; }
+        else if (hit == NIL) bad = 1;
+        else {
+          uint32_t cnt = 0, only = NIL;
+          for (uint32_t c = 0; c < 4; ++c) { const idx_t v = pidx[4 * hit + c]; if (v != NONE) { ++cnt; only = (uint32_t)v; } }
+          if (cnt == 1 && only < n_ref) scal[4] = only; else bad = 1;
+        }
+      }
+      if (!__syncthreads_or((int)bad)) {
+        const uint32_t fa = scal[3], fb = scal[4];
+        if (fa < fb && fb <= n_ref - 1 && (uint64_t)(fb - fa) + 10 <= 100ull * (m - n_ref + 1)) {   // block-uniform
+          emit_bubble(fa, fb);
+          return;
+        }
+      }
+    }
+  }
   // ---- 2. adjacency: succ[4j+c] = node of kmer[j][1:]+c ; pred[4v+f] = j, f = first base of j
   for (uint32_t j = tid; j < m; j += NT) {
     const uint64_t X = nk(j);
@@ -613,40 +710,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     }
     __syncthreads();
     if (scal[2]) {
-      const uint32_t fa = scal[3], fb = scal[4];
-      // min coverage of the two paths: wave 0 the reference path, wave 1 the path through the bubble
-      if (wave < 2) {
-        uint32_t mc = 0xFFFFFFFFu;
-        auto over = [&](uint32_t lo, uint32_t hi) {            // [lo, hi)
-          for (uint32_t q = lo + lane; q < hi; q += 64) { const uint32_t c = ncnt[q]; mc = c < mc ? c : mc; }
-        };
-        if (wave == 0) over(0, n_ref);
-        else { over(0, fa + 1); over(n_ref, m); over(fb, n_ref); }
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mc, o); mc = other < mc ? other : mc; }
-        if (lane == 0) scal[5 + wave] = mc;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long path_base = atomicAdd(&ctr[0], 2ull);
-        unsigned long long run_base = atomicAdd(&ctr[1], 4ull);
-        if (path_base + 2 > pg_paths || run_base + 4 > pg_runs) {
-          atomicExch(ovf, 1ull);               // pools exhausted: host enlarges them and reruns the stage
-          a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0;
-        } else {
-          path_base += (uint64_t)pg * pg_paths;
-          run_base += (uint64_t)pg * pg_runs;
-          a.r_start[run_base] = 0; a.r_len[run_base] = n_ref;
-          a.p_target[path_base] = t; a.p_runbase[path_base] = run_base; a.p_nruns[path_base] = 1;
-          a.p_len[path_base] = n_ref; a.p_mincov[path_base] = scal[5];
-          a.r_start[run_base + 1] = 0; a.r_len[run_base + 1] = fa + 1;
-          a.r_start[run_base + 2] = n_ref; a.r_len[run_base + 2] = m - n_ref;
-          a.r_start[run_base + 3] = fb; a.r_len[run_base + 3] = n_ref - fb;
-          a.p_target[path_base + 1] = t; a.p_runbase[path_base + 1] = run_base + 1; a.p_nruns[path_base + 1] = 3;
-          a.p_len[path_base + 1] = (fa + 1) + (m - n_ref) + (n_ref - fb); a.p_mincov[path_base + 1] = scal[6];
-          a.t_npaths[t] = 2; a.t_pathbase[t] = (uint32_t)path_base; a.t_nruns[t] = 4;
-        }
-        a.g_status[t] = T_OK;
-      }
+      emit_bubble(scal[3], scal[4]);
       return;
     }
   }
