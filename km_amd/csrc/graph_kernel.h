@@ -378,6 +378,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   if (a.dbg == 9) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   uint32_t shared_prefix = 0;            // some other node has the same (k-1)-mer prefix
   uint32_t own_slot[MAXOWN];             // FUSED: 4 * slot + last base of this thread's nodes
+  uint64_t own_x[MAXOWN];                // FUSED: their k-mers (2c' looks up the suffixes of the walk's nodes)
   if constexpr (FUSED) {
     if (m > MAXOWN * NT) {                 // cannot happen with the LDS tier's geometry
       if (tid == 0) { a.g_status[t] = T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
@@ -387,9 +388,11 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     for (uint32_t q = 0; q < MAXOWN; ++q) {
       const uint32_t j = tid + q * NT;
       own_slot[q] = 0;
+      own_x[q] = 0;
       if (j < m) {
         bool wn;
         const uint64_t X = nk(j);
+        own_x[q] = X;
         const int s = set_insert_lane(pkeys, hcap, X >> 2, &wn);
         if (s < 0 || !wn) shared_prefix = 1;
         own_slot[q] = 4u * (uint32_t)(s < 0 ? 0 : s) + (uint32_t)(X & 3);
@@ -553,7 +556,8 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   // graph has the reference edges j -> j+1, the chain a -> n_ref -> .. -> m-1 -> b and nothing
   // else: any other edge would put a second node into a prefix slot that (R1)-(R4) say holds one.
   // All of it is in the table already: how many nodes share a node's prefix is the number of
-  // occupied indices of its slot (kept in own_slot), and two lookups give (R1)'s and (R4)'s rest.
+  // occupied indices of its slot (kept in own_slot); (R3) and (R4) are one lookup per walk node of
+  // its own suffix (its slot must hold exactly the next walk node, resp. b), (R1)'s rest one more.
   if constexpr (FUSED) {
     if (a.dbg == 0 && m > n_ref && n_ref >= 2) {
       uint32_t bad = 0;
@@ -575,24 +579,27 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
           else if (j < n_ref) { if (other != n_ref) bad = 1; }
           else bad = 1;                                           // a later walk node shares its prefix
         } else if (j == n_ref) bad = 1;                           // the first walk node hangs off nothing
-        if (j > n_ref && (nk(j) >> 2) != (nk(j - 1) & a.pmask)) bad = 1;   // (R3)
-      }
-      if (tid == 0 || tid == 64) {
-        // (R1): suffix of the last reference k-mer absent; (R4): suffix of the last walk node -> b
-        const uint64_t S = nk(tid == 0 ? n_ref - 1 : m - 1) & a.pmask;
-        uint32_t s = set_home(S, hcap), hit = NIL;
-        for (uint32_t step = 0; step < hcap; ++step) {
-          const uint64_t kv = pkeys[s];
-          if (kv == S) { hit = s; break; }
-          if (kv == EMPTY) break;
-          if (++s == hcap) s = 0;
-        }
-        if (tid == 0) { if (hit != NIL) bad = 1; }
-        else if (hit == NIL) bad = 1;
-        else {
-          uint32_t cnt = 0, only = NIL;
-          for (uint32_t c = 0; c < 4; ++c) { const idx_t v = pidx[4 * hit + c]; if (v != NONE) { ++cnt; only = (uint32_t)v; } }
-          if (cnt == 1 && only < n_ref) scal[4] = only; else bad = 1;
+        // the suffix of a walk node is the prefix of exactly the next one (R3), of exactly one
+        // reference node for the last (R4); of nobody for the last reference node (R1)
+        if (j >= n_ref - 1) {
+          const uint64_t S = own_x[q] & a.pmask;
+          uint32_t s = set_home(S, hcap), hit = NIL;
+          for (uint32_t step = 0; step < hcap; ++step) {
+            const uint64_t kv = pkeys[s];
+            if (kv == S) { hit = s; break; }
+            if (kv == EMPTY) break;
+            if (++s == hcap) s = 0;
+          }
+          if (j == n_ref - 1) { if (hit != NIL) bad = 1; }
+          else if (hit == NIL) bad = 1;
+          else {
+            uint32_t n_in = 0, only = NIL;
+            for (uint32_t c = 0; c < 4; ++c) { const idx_t v = pidx[4 * hit + c]; if (v != NONE) { ++n_in; only = (uint32_t)v; } }
+            if (n_in != 1) bad = 1;
+            else if (j + 1 < m) { if (only != j + 1) bad = 1; }
+            else if (only < n_ref) scal[4] = only;
+            else bad = 1;
+          }
         }
       }
       if (!__syncthreads_or((int)bad)) {
