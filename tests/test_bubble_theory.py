@@ -1,0 +1,97 @@
+"""The closed form k_graph uses for "reference chain + one forward bubble" (graph_kernel.h, 2c'
+and 2c), checked on the CPU against the oracle's restatement of the reference algorithm
+(oracle/km_oracle.py: graph_paths = Graph.py:63-240): whenever the shape conditions hold on a node
+list — stated here exactly as the kernel reads them off its prefix table — the paths must be the
+reference path and the one path through the bubble, nothing else.  Random node lists come from the
+oracle's own walk over seeded synthetic databases (several variants per target, sibling noise,
+small k for chance overlaps), so that most shapes do NOT qualify; those are only counted."""
+import numpy as np
+import pytest
+
+from km_amd import kmer as km
+from km_amd import synth
+from oracle import km_oracle as ko
+
+
+def bubble_shape(kmers, n_ref):
+    """(a, b) if the node list is the reference chain plus one forward bubble by the kernel's
+    conditions (R1)-(R4) and the cost margin, else None."""
+    m = len(kmers)
+    if not (m > n_ref >= 2):
+        return None
+    by_prefix = {}
+    for i, mer in enumerate(kmers):
+        by_prefix.setdefault(mer[:-1], []).append(i)
+    a = None
+    for j, mer in enumerate(kmers):
+        share = by_prefix[mer[:-1]]
+        if len(share) > 2:
+            return None
+        if len(share) == 2:
+            other = share[0] if share[1] == j else share[1]
+            if j == n_ref:
+                if not (1 <= other <= n_ref - 1):
+                    return None
+                a = other - 1
+            elif j < n_ref:
+                if other != n_ref:
+                    return None
+            else:
+                return None
+        elif j == n_ref:
+            return None
+    if by_prefix.get(kmers[n_ref - 1][1:]):            # (R1) nothing behind the last reference suffix
+        return None
+    b = None
+    for e in range(n_ref, m):                           # (R3) / (R4)
+        behind = by_prefix.get(kmers[e][1:], [])
+        if len(behind) != 1:
+            return None
+        if e + 1 < m:
+            if behind[0] != e + 1:
+                return None
+        elif behind[0] < n_ref:
+            b = behind[0]
+        else:
+            return None
+    if a is None or b is None or not (a < b <= n_ref - 1):
+        return None
+    if (b - a) + 10 > 100 * (m - n_ref + 1):
+        return None
+    return a, b
+
+
+@pytest.mark.parametrize("k", [9, 13, 21, 31])
+def test_closed_form_equals_the_reference_algorithm(k):
+    rng = np.random.default_rng(9000 + k)
+    n_shape = n_other = 0
+    for trial in range(24):
+        spec = dict(n_targets=14, length=int(rng.integers(3 * k + 8, 260)), k=k, n_keys=3000,
+                    seed=int(rng.integers(1, 1 << 30)), variant_frac=0.9,
+                    variants_per_target=(1, int(rng.integers(1, 3))), vaf=(0.1, 0.9),
+                    hom_frac=float(rng.choice([0.0, 0.3])), branch_noise_frac=float(rng.choice([0.0, 0.05])),
+                    noise_frac=float(rng.choice([0.0, 0.05])), cov=(30, 400))
+        case = synth.make_case(**spec)
+        db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                       records={"k": k, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+        for row, name in zip(case["targets"], case["names"]):
+            seq = km.decode(row)
+            try:
+                mers = ko.ref_kmers(seq, name, k)
+                nodes = ko.walk(mers, db)
+            except (ValueError, ko.NodeLimit):
+                continue
+            kmers = list(nodes.keys())
+            n_ref = len(mers)
+            shape = bubble_shape(kmers, n_ref)
+            if shape is None:
+                n_other += 1
+                continue
+            n_shape += 1
+            a, b = shape
+            m = len(kmers)
+            want = sorted([tuple(range(n_ref)),
+                           tuple(range(a + 1)) + tuple(range(n_ref, m)) + tuple(range(b, n_ref))])
+            got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
+            assert got == want, (k, trial, name, a, b, n_ref, m)
+    assert n_shape >= 10 and n_other >= 10, (n_shape, n_other)       # both sides of the conditions were met
