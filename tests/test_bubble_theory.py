@@ -95,3 +95,84 @@ def test_closed_form_equals_the_reference_algorithm(k):
             got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
             assert got == want, (k, trial, name, a, b, n_ref, m)
     assert n_shape >= 10 and n_other >= 10, (n_shape, n_other)       # both sides of the conditions were met
+
+
+def bubbles_shape(kmers, n_ref):
+    """Generalisation (not in the kernel yet): the reference chain plus ANY number of
+    forward bubbles, each a run of consecutive walk nodes s..e hanging off reference node a and
+    leading back to reference node b > a.  Returns [(a, s, e, b)] or None."""
+    m = len(kmers)
+    if not (m > n_ref >= 2):
+        return None
+    by_prefix = {}
+    for i, mer in enumerate(kmers):
+        by_prefix.setdefault(mer[:-1], []).append(i)
+    if by_prefix.get(kmers[n_ref - 1][1:]):
+        return None
+    head_of = {}                                        # walk node -> a
+    for j, mer in enumerate(kmers):
+        share = by_prefix[mer[:-1]]
+        if len(share) > 2:
+            return None
+        if len(share) == 2:
+            other = share[0] if share[1] == j else share[1]
+            if j >= n_ref:
+                if not (1 <= other <= n_ref - 1):
+                    return None                         # two walk nodes share a prefix
+                head_of[j] = other - 1
+            elif other < n_ref:
+                return None                             # two reference nodes share a prefix
+    bubbles, e = [], n_ref
+    while e < m:
+        if e not in head_of:
+            return None                                 # a chain must start at a head
+        a, s = head_of[e], e
+        while True:
+            behind = by_prefix.get(kmers[e][1:], [])
+            if len(behind) != 1:
+                return None
+            nxt = behind[0]
+            if nxt < n_ref:
+                b = nxt
+                break
+            if nxt != e + 1 or nxt in head_of:
+                return None
+            e = nxt
+        if not (a < b <= n_ref - 1) or (b - a) + 10 > 100 * (e - s + 2):
+            return None
+        bubbles.append((a, s, e, b))
+        e += 1
+    return bubbles
+
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+def test_closed_form_for_several_bubbles(k):
+    """The same argument carries to several forward bubbles (each one more path through exactly that
+    bubble): checked here against the oracle so that the next kernel step starts from a proven form."""
+    rng = np.random.default_rng(9500 + k)
+    n_multi = 0
+    for trial in range(22):
+        spec = dict(n_targets=12, length=int(rng.integers(5 * k + 8, 320)), k=k, n_keys=3000,
+                    seed=int(rng.integers(1, 1 << 30)), variant_frac=1.0, variants_per_target=(2, 3),
+                    kinds=("snv", "ins", "del"), vaf=(0.2, 0.8), noise_frac=0.0, cov=(60, 400))
+        case = synth.make_case(**spec)
+        db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                       records={"k": k, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+        for row, name in zip(case["targets"], case["names"]):
+            seq = km.decode(row)
+            try:
+                mers = ko.ref_kmers(seq, name, k)
+                nodes = ko.walk(mers, db)
+            except (ValueError, ko.NodeLimit):
+                continue
+            kmers = list(nodes.keys())
+            n_ref = len(mers)
+            shape = bubbles_shape(kmers, n_ref)
+            if shape is None:
+                continue
+            n_multi += len(shape) > 1
+            want = sorted([tuple(range(n_ref))] +
+                          [tuple(range(a + 1)) + tuple(range(s, e + 1)) + tuple(range(b, n_ref)) for a, s, e, b in shape])
+            got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
+            assert got == want, (k, trial, name, shape, n_ref, len(kmers))
+    assert n_multi >= 10, n_multi
