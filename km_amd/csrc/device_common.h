@@ -465,97 +465,98 @@ __device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCa
   p->a1 = q[1];
   p->valid = true;
 }
-// Key state along a CHAIN (k_dfs walking a run of single children): the key of
-// child = x[1:] + c follows from the key state of x with a handful of scalar operations.
-// The reverse complement shifts in one base; of the w windows only the last one is new, so the
-// minimizer is the old one moved one position to the left unless the new window beats it — or
-// the old one has just left the k-mer (one step in ~w), which costs the full wave-wide search.
-struct ChainKey {
-  uint64_t R;        // revcomp of the (k-1)-mer whose group was requested last
-  uint32_t best;     // selection key of its minimizer (position in the low bits)
-  uint32_t bc, bs;   // canonical m-mer and strand of the minimizer
-  uint32_t bucket;
-};
 __device__ inline uint32_t lane_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ inline uint64_t lane_u64(uint64_t v, uint32_t l) {
   return ((uint64_t)lane_u32((uint32_t)(v >> 32), l) << 32) | lane_u32((uint32_t)v, l);
 }
-// ck <- key state of the group of the (k-1)-mer P, from scratch
-__device__ inline void chain_key_init(const TableView& t, ChainKey* ck, uint64_t P) {
-  ck->R = revcomp(P, t.k - 1);
-  minimizer_wave(t, P, ck->R, &ck->best, &ck->bc, &ck->bs);
-  ck->bucket = bucket_of(t, ck->bc);
-}
-// ck <- key state of the group of child = x[1:] + c (P = child & pmask), from the key state of x's group
-__device__ inline void chain_key_step(const TableView& t, ChainKey* ck, uint64_t P, uint32_t c) {
-  const uint64_t R = (ck->R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
-  uint32_t best, bc, bs, bucket;
-  if ((ck->best & SEL_POS) != 0) {
-    const uint32_t f = (uint32_t)P & t.mmask;
-    const uint32_t r = (uint32_t)(R >> (2 * (t.w - 1))) & t.mmask;
-    const uint32_t cn = f < r ? f : r;
-    const uint32_t seln = (mm_order(cn) & ~SEL_POS) | (uint32_t)(t.w - 1);
-    best = ck->best - 1u;                        // same window, one position further left
-    bc = ck->bc; bs = ck->bs; bucket = ck->bucket;
-    if (seln < best) {
-      best = seln; bc = cn; bs = f < r ? 0u : 1u;
-      bucket = bucket_of(t, bc);
-    }
-  } else {                                       // the minimizer was x's first window: search again
-    minimizer_wave(t, P, R, &best, &bc, &bs);
-    bucket = bucket_of(t, bc);
-  }
-  ck->R = R; ck->best = best; ck->bc = bc; ck->bs = bs; ck->bucket = bucket;
+// bucket of the group of the (k-1)-mer P (wave-uniform; the windows are spread over the lanes)
+__device__ inline uint32_t bucket_of_wave(const TableView& t, uint64_t P) {
+  const uint64_t R = revcomp(P, t.k - 1);
+  uint32_t best, bc, bs;
+  minimizer_wave(t, P, R, &best, &bc, &bs);
+  return bucket_of(t, bc);
 }
 
-// ---- A bucket held in the wave's registers (k_dfs chain runs).  The k-mers of a chain share
-// their minimizer for ~w/2 steps, and with it the bucket: lane j keeps slot j of that bucket, so
-// that a lookup is one compare of the tag against all its slots — no hashing to a home pair, no
-// memory access, no latency — until the minimizer changes.  A key never leaves its bucket
-// (probing wraps inside it), so "some slot of the bucket holds the tag" is exactly the table's
-// own answer.  Buckets of more than 64 slots are not held (resident = false).
-constexpr uint32_t BUCKET_LANES_SETS = 4;          // slots per lane: buckets of up to 256 slots are held
+// ---- A bucket held in the wave's registers, with every slot's SUCCESSOR worked out in advance
+// (k_dfs chain runs).  The k-mers of a chain share their minimizer for ~w/2 steps, and with it the
+// bucket: lane j keeps slot j of that bucket.  A slot {tag, four counts} is everything get_child
+// (km/utils/Jellyfish.py:55-72) looks at for the k-mers x with x[1:] = the slot's (k-1)-mer, so the
+// lane that loads a slot also evaluates it, once, for all 64 slots at a time and off the walk's
+// critical path: the threshold, the kept children, and — when exactly one child is kept — that
+// child's base and count, the TAG OF THE GROUP THE WALK LOOKS UP NEXT, and whether the child sits
+// in its home slot of the node set (a likely rejoin).  A chain step is then: compare the tag against
+// the lanes (one v_cmp + ballot), read the hit lane's three words.  No hashing, no arithmetic on
+// counts, no memory access, until the tag is not among the lanes: then either the minimizer has
+// changed (the next bucket is loaded and evaluated) or the group does not exist.  A key never
+// leaves its bucket (probing wraps inside it), so "some slot of the bucket holds the tag" is exactly
+// the table's own answer.  Buckets of more than 64 * BUCKET_LANES_SETS slots are not held.
+constexpr uint32_t BUCKET_LANES_SETS = 9;          // slots per lane: buckets of up to 576 slots are held (a crowded
+                                                   // bucket of the usual size, 4 * 128 + NC = 544 slots, fits)
+constexpr uint32_t SLOT_SINGLE = 4u, SLOT_HINT = 8u;
 struct BucketLanes {
-  uint64_t tag[BUCKET_LANES_SETS], zw[BUCKET_LANES_SETS];   // lane j, set i: slot 64 i + j (tag = EMPTY past the end)
+  uint64_t tag[BUCKET_LANES_SETS];                           // lane j, set i: slot 64 i + j (EMPTY past the end)
+  uint64_t ntag[BUCKET_LANES_SETS];                          // tag of the group of the single kept child's suffix
+  uint32_t info[BUCKET_LANES_SETS];                          // child base | SLOT_SINGLE | SLOT_HINT | count << 16
   uint32_t bucket, S;    // wave-uniform
   bool valid, resident;
 };
-__device__ inline void bucket_load_wave(const TableView& t, uint32_t bucket, BucketLanes* b, uint32_t* fetches) {
-  const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + bucket);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.lo);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.hi);
+struct ChildRule {       // what get_child needs beside the counts (wave-uniform)
+  double ratio;
+  int64_t n_cutoff;
+  uint64_t thr_below;    // sums below it share the threshold thr_T (threshold_shortcut)
+  uint32_t thr_T;
+};
+// One slot evaluated by its lane.  `keys` / `cap`: the walk's node set (the hint only).
+__device__ inline uint32_t set_home(uint64_t key, uint32_t cap);
+__device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
+                                      const uint64_t* keys, uint32_t cap, uint64_t* ntag, uint32_t* info);
+// lo / hi: the bucket's directory words (wave-uniform)
+__device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, uint32_t bucket, uint32_t lo, uint32_t hi,
+                                        const uint64_t* keys, uint32_t cap, BucketLanes* b, uint32_t* fetches) {
   const uint32_t S = 2u * (hi - lo);
   b->bucket = bucket; b->S = S; b->valid = true; b->resident = S <= 64u * BUCKET_LANES_SETS;
   if (b->resident) {
     const uint32_t lane = (uint32_t)lane_id();
+    uint64_t zw[BUCKET_LANES_SETS];
+    // all the loads first (independent), then the evaluation
 #pragma unroll
     for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
-      b->tag[i] = EMPTY; b->zw[i] = 0;
+      b->tag[i] = EMPTY; b->ntag[i] = EMPTY; b->info[i] = 0; zw[i] = 0;
       if (64u * i < S) {                             // wave-uniform
         if (64u * i + lane < S) {
           const uint4 v = *reinterpret_cast<const uint4*>(t.slots + 2ull * lo + 64u * i + lane);
           b->tag[i] = ((uint64_t)v.y << 32) | v.x;
-          b->zw[i] = ((uint64_t)v.w << 32) | v.z;
+          zw[i] = ((uint64_t)v.w << 32) | v.z;
         }
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
+      if (64u * i < S) {                             // wave-uniform
+        if (b->tag[i] != EMPTY) slot_successor(t, r, b->tag[i], zw[i], keys, cap, &b->ntag[i], &b->info[i]);
       }
     }
     *fetches += S;
   }
 }
-// count words of the group `tag` in a resident bucket (0 if absent)
-__device__ inline uint64_t bucket_find_wave(const BucketLanes& b, uint64_t tag) {
-  static_assert(BUCKET_LANES_SETS == 4, "unrolled by hand");
-  unsigned long long hit = __ballot(b.tag[0] == tag);
-  if (hit) return lane_u64(b.zw[0], (uint32_t)__ffsll((long long)hit) - 1);
-  if (b.S <= 64u) return 0;
-  hit = __ballot(b.tag[1] == tag);
-  if (hit) return lane_u64(b.zw[1], (uint32_t)__ffsll((long long)hit) - 1);
-  if (b.S <= 128u) return 0;
-  hit = __ballot(b.tag[2] == tag);
-  if (hit) return lane_u64(b.zw[2], (uint32_t)__ffsll((long long)hit) - 1);
-  hit = __ballot(b.tag[3] == tag);
-  if (hit) return lane_u64(b.zw[3], (uint32_t)__ffsll((long long)hit) - 1);
-  return 0;
+// the slot of the group `tag` in a resident bucket
+struct SlotHit { uint64_t ntag; uint32_t info; bool hit; };
+__device__ inline SlotHit bucket_find_wave(const BucketLanes& b, uint64_t tag) {
+  SlotHit h;
+  h.hit = false; h.info = 0; h.ntag = EMPTY;
+#pragma unroll
+  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
+    if (!h.hit && 64u * i < b.S) {                   // wave-uniform
+      const unsigned long long hit_ = __ballot(b.tag[i] == tag);
+      if (hit_) {
+        const uint32_t l_ = (uint32_t)__ffsll((long long)hit_) - 1;
+        h.info = lane_u32(b.info[i], l_);
+        h.ntag = lane_u64(b.ntag[i], l_);
+        h.hit = true;
+      }
+    }
+  }
+  return h;
 }
 // canonical tag of the group of the (k-1)-mer P (R = its reverse complement)
 __device__ inline uint64_t group_tag(const TableView& t, uint64_t P, uint64_t R, uint32_t* flip) {
@@ -622,6 +623,47 @@ __device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) {
   if (none) return 0u;
   return (c.x >= T ? 1u : 0u) | (c.y >= T ? 2u : 0u) | (c.z >= T ? 4u : 0u) | (c.w >= T ? 8u : 0u);
 }
+// device_common.h: BucketLanes.  What Jellyfish.get_child (km/utils/Jellyfish.py:55-72) makes of one
+// slot, for the k-mers x whose suffix x[1:] is the slot's (k-1)-mer in the orientation its side bit names.
+__device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
+                                      const uint64_t* keys, uint32_t cap, uint64_t* ntag, uint32_t* info) {
+  const uint32_t z = (uint32_t)zw, w = (uint32_t)(zw >> 32);
+  const uint32_t s0 = z & 0xFFFFu, s1 = z >> 16, s2 = w & 0xFFFFu, s3 = w >> 16;   // slot order
+  const bool esc = s0 == COUNT_ESCAPE || s1 == COUNT_ESCAPE || s2 == COUNT_ESCAPE || s3 == COUNT_ESCAPE;
+  const uint64_t sum = (uint64_t)(s0 + s1 + s2 + s3);
+  uint32_t T = r.thr_T;
+  bool none = false;
+  if (sum >= r.thr_below) T = child_threshold(sum, r.ratio, r.n_cutoff, &none);
+  uint32_t m4 = (s0 >= T ? 1u : 0u) | (s1 >= T ? 2u : 0u) | (s2 >= T ? 4u : 0u) | (s3 >= T ? 8u : 0u);
+  if (none) m4 = 0;
+  const bool single = !esc && m4 != 0 && (m4 & (m4 - 1)) == 0;
+  *info = 0;
+  *ntag = EMPTY;
+  if (!single) return;
+  const uint32_t si = (uint32_t)__ffs((int)m4) - 1;
+  const uint32_t side = t.canonical ? (uint32_t)(tag & 1) : 0u;
+  const uint32_t c = side ? 3u - si : si;                        // child base
+  const uint32_t cnt = (uint32_t)(zw >> (16 * si)) & 0xFFFFu;
+  const uint64_t G = tag >> 1;
+  // P: the (k-1)-mer as the walk reads it (x[1:]); R: its reverse complement
+  uint64_t P = G, R = 0;
+  if (t.canonical) {
+    const uint64_t Grc = revcomp(G, t.k - 1);
+    P = side ? Grc : G;
+    R = side ? G : Grc;
+  }
+  const uint64_t child = (P << 2) | c;                           // x[1:] + c, 2k bits
+  const uint64_t P2 = child & t.pmask;
+  uint64_t nt = P2 << 1;
+  if (t.canonical) {
+    const uint64_t R2 = (R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
+    if (R2 < P2) nt = (R2 << 1) | 1ull;
+  }
+  *ntag = nt;
+  const bool hint = keys[set_home(child, cap)] == child;
+  *info = c | SLOT_SINGLE | (hint ? SLOT_HINT : 0u) | (cnt << 16);
+}
+
 // Sums below *below* all have the threshold T = ceil(n_cutoff) (sum * ratio <= n_cutoff: the float64
 // product is monotone in the sum for ratio >= 0), so that a walk step can skip the float64 arithmetic
 // for them.  0 = no such shortcut (negative or NaN ratio).

@@ -69,7 +69,7 @@ struct WalkArgs {
   uint32_t max_stack, max_break, max_node;
   // k_seed work items: one self-contained 128-byte record per SEED_BLOCK seeds, written
   // by k_pack: [0] target | first seed << 32, [1] n_ref | valid << 32, [2] node base,
-  // [3] flag-word offset, [4..15] the 12 packed words covering the item's k-mers
+  // [3] flag-word offset | packed-word offset << 32, [4..15] the 12 packed words covering the item's k-mers
   uint64_t* items;
   const uint32_t* item_off;   // first item of each target
   uint32_t n_items;
@@ -79,6 +79,11 @@ struct WalkArgs {
   uint32_t* tflag;            // per target: already in the flagged list
   uint32_t* flagged;          // list of flagged targets (any order)
   uint32_t* n_flagged;        // device counter
+  // what k_dfs needs to start on entry i of that list, in one 32-byte record written by k_seed
+  // (instead of a chain of dependent header loads): {t, n_ref, node base lo / hi} {flag-word
+  // offset, packed-word offset, 0, 0}
+  uint4* flag_rec;
+  uint32_t fast_extra;        // fast tier: a target's node storage holds n_ref + fast_extra nodes
   // k_dfs target selection: list + count (device counter or host value)
   const uint32_t* list;
   const uint32_t* n_list_dev;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
       if (f == 0) v = (uint64_t)t | ((uint64_t)(q * SEED_BLOCK) << 32);
       else if (f == 1) v = (uint64_t)n_ref | ((uint64_t)(st == T_OK ? 1u : 0u) << 32);
       else if (f == 2) v = nbase;
-      else if (f == 3) v = fwo;
+      else if (f == 3) v = fwo | (wo << 32);       // both below 2^32 (km_batch_create checks)
       else {
         const uint32_t w = q * (SEED_BLOCK / 32) + (f - 4);
         v = (w <= nwords) ? (in_lds ? mine[w] : a.packed[wo + w]) : 0ull;
@@ -339,7 +344,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   if (tid < W) raw[SEED_BLOCK + tid] = mmer_scan_key(tab, bits_at(SEED_BLOCK + tid), SEED_BLOCK + tid);
   // the record header is only needed from here on: its load overlapped the bases above
   const uint64_t h0 = rec[0], h1 = rec[1];
-  const uint64_t nb = rec[2], fwo = rec[3];
+  const uint64_t nb = rec[2], fwo = rec[3] & 0xFFFFFFFFull;
+  const uint32_t wo32 = (uint32_t)(rec[3] >> 32);
   if ((uint32_t)(h1 >> 32) == 0u) return;                  // target not walkable (status != OK); block-uniform
   const uint32_t t = (uint32_t)h0;
   const uint32_t n_ref = (uint32_t)h1;
@@ -432,7 +438,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
       triv_child = triv && mask != 0;
       if (!triv) {
         atomicOr(&a.flagbits[fwo + (i >> 5)], 1u << (i & 31));
-        if (atomicExch(&a.tflag[t], 1u) == 0u) a.flagged[atomicAdd(a.n_flagged, 1u)] = t;
+        if (atomicExch(&a.tflag[t], 1u) == 0u) {
+          const uint32_t at = atomicAdd(a.n_flagged, 1u);
+          a.flagged[at] = t;
+          a.flag_rec[2 * at] = make_uint4(t, n_ref, (uint32_t)nb, (uint32_t)(nb >> 32));
+          a.flag_rec[2 * at + 1] = make_uint4((uint32_t)fwo, wo32, 0u, 0u);
+        }
       }
     }
   }
@@ -490,13 +501,40 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
 template <bool BIG, int K>
 __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef KM_DFS_STAMPS
+  uint32_t dfs_entry;
+  {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    dfs_entry = (uint32_t)t_;
+  }
+#endif
   const uint32_t lane = (uint32_t)lane_id();
-  const uint32_t n_list = a.n_list_dev ? *a.n_list_dev : a.n_list_host;
-  if (blockIdx.x >= n_list) return;
-  const uint32_t t = a.list[blockIdx.x];
-  if (a.status[t] != T_OK && a.status[t] != T_NEEDS_BIG) return;
   const TableView tab = specialized_view<K>(a.tab);
   const int k = tab.k;
+  // the target: fast tier — entry blockIdx.x of k_seed's list of flagged targets, with what the
+  // walk needs of it in one record (requested together with the length of the list); large tier —
+  // a list of target ids from the host
+  uint32_t t, n_ref, node_cap;
+  uint64_t nb, wo, fwo;
+  if constexpr (BIG) {
+    const uint32_t n_list = a.n_list_dev ? *a.n_list_dev : a.n_list_host;
+    if (blockIdx.x >= n_list) return;
+    t = a.list[blockIdx.x];
+    if (a.status[t] != T_OK && a.status[t] != T_NEEDS_BIG) return;
+    n_ref = a.n_ref[t];
+    nb = a.node_base[t];
+    node_cap = a.node_cap[t];
+    wo = a.woff[t];
+    fwo = a.fw_off[t];
+  } else {
+    const uint4 r0 = a.flag_rec[2 * blockIdx.x], r1 = a.flag_rec[2 * blockIdx.x + 1];
+    const uint32_t n_list = *a.n_list_dev;
+    if (blockIdx.x >= n_list) return;
+    t = r0.x; n_ref = r0.y; nb = ((uint64_t)r0.w << 32) | r0.z;
+    fwo = r1.x; wo = r1.y;
+    node_cap = n_ref + a.fast_extra;
+  }
 
   unsigned char* wsb;
   unsigned char* fwb;
@@ -525,13 +563,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   };
   auto mem_sync = [&]() { __syncthreads(); };
 
-  const uint64_t L = a.toff[t + 1] - a.toff[t];
-  const uint32_t n_ref = a.n_ref[t];
-  const uint64_t nb = a.node_base[t];
-  const uint32_t node_cap = a.node_cap[t];
-  const uint32_t nwords = (uint32_t)((L + 31) >> 5);
+  // a flagged target is walkable: n_ref >= 1 and L = n_ref + k - 1 bases
+  const uint32_t nwords = (uint32_t)(((uint64_t)n_ref + (uint32_t)k - 1 + 31) >> 5);
   const uint32_t nflag = (n_ref + 31) >> 5;
-  const uint32_t* flag = a.flagbits + a.fw_off[t];
+  const uint32_t* flag = a.flagbits + fwo;
   if (nwords + 1 > a.words_cap || n_ref > node_cap || (uint64_t)n_ref * 4 > (uint64_t)cap * 3) {
     if (lane == 0) a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG;
     return;
@@ -539,10 +574,19 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   if (a.dbg & 1u) return;
 
   // ---- per-target state: packed target + node set of the target's k-mers ------------
-  for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
-  {
-    const uint64_t wo = a.woff[t];
-    for (uint32_t w = lane; w <= nwords; w += 64) words[w] = a.packed[wo + w];
+  // the flag words are requested now (lane w: word w of each chunk of 64) and looked at after the set is built
+  uint32_t flag0 = 0;
+  if (lane < nflag) flag0 = flag[lane];
+  for (uint32_t w = lane; w <= nwords; w += 64) words[w] = a.packed[wo + w];
+  if constexpr (BIG) {
+    for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
+  } else {
+    // LDS: 16 bytes per store (cap is a multiple of 64: whole uint4s in both arrays)
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint4* kq = reinterpret_cast<uint4*>(keys);
+    for (uint32_t s = lane; s < cap / 2; s += 64) kq[s] = ones;
+    uint4* sq = reinterpret_cast<uint4*>(state);
+    for (uint32_t s = lane; s < cap / 16; s += 64) sq[s] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
   auto kmer_at = [&](uint32_t i) -> uint64_t {
@@ -552,11 +596,35 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     return x >> (64 - 2 * k);
   };
   uint32_t dup = 0;
-  for (uint32_t i = lane; i < n_ref; i += 64) {
-    bool was_new;
-    const int s = set_insert_lane(keys, cap, kmer_at(i), &was_new);
-    if (s >= 0 && was_new) state[s] = (uint8_t)ST_NODE;
-    if (s < 0 || !was_new) dup = 1;
+  // four k-mers per lane and round: their first compare-and-swaps are in flight together (an LDS
+  // atomic returns after ~130 cycles; one after the other they were a quarter of the kernel's
+  // fixed cost); the few that find their home slot taken probe on afterwards
+  for (uint32_t i0 = lane; i0 < n_ref; i0 += 256) {
+    uint64_t kk[4];
+    uint32_t hs[4];
+    unsigned long long old[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + 64 * u;
+      kk[u] = i < n_ref ? kmer_at(i) : 0;
+      hs[u] = set_home(kk[u], cap);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      old[u] = EMPTY;
+      if (i0 + 64 * u < n_ref)
+        old[u] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[hs[u]]), (unsigned long long)EMPTY, (unsigned long long)kk[u]);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (i0 + 64 * u >= n_ref) continue;
+      if (old[u] == EMPTY) { state[hs[u]] = (uint8_t)ST_NODE; continue; }
+      if (old[u] == kk[u]) { dup = 1; continue; }
+      bool was_new;
+      const int s = set_insert_lane(keys, cap, kk[u], &was_new);
+      if (s >= 0 && was_new) state[s] = (uint8_t)ST_NODE;
+      if (s < 0 || !was_new) dup = 1;
+    }
   }
   __syncthreads();
 
@@ -565,16 +633,25 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   DirCache dcache = {~0u, 0u, 0u};
   PendingLookup pend;
   pend.valid = false;
+  // the bucket the chain runs hold in the lanes outlives a run: the next one mostly starts where
+  // this one ended (its rejoin hints may then be stale — they are hints)
+  BucketLanes bl;
+  bl.valid = false; bl.resident = false; bl.bucket = 0; bl.S = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) { bl.tag[i] = EMPTY; bl.ntag[i] = EMPTY; bl.info[i] = 0; }
+  const ChildRule rule = {a.ratio, a.n_cutoff, a.thr_below, a.thr_T};
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
 #ifdef KM_DFS_STAMPS
-  uint32_t dfs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dfs_prev, dfs_t0, dfs_steps = 0;   // 32 bits: few SGPRs
-  uint32_t dfs_loads = 0, dfs_nonres = 0, dfs_maxS = 0;
+  uint32_t dfs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dfs_prev, dfs_t0, dfs_steps = 0;   // 32 bits: few SGPRs
+  uint32_t dfs_general = 0, dfs_runs = 0;
+  uint32_t dfs_loads = 0, dfs_nonres = 0, dfs_maxS = 0, dfs_t_setup;
+  dfs_t0 = dfs_entry;
   {
     unsigned long long t_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-    dfs_t0 = dfs_prev = (uint32_t)t_;
+    dfs_t_setup = dfs_prev = (uint32_t)t_;
   }
 #endif
 
@@ -584,7 +661,9 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     const uint32_t set_limit = (uint32_t)(((uint64_t)cap * 3) >> 2);
     uint64_t steps = 0;
     for (uint32_t w = 0; w < nflag && st == T_OK; ++w) {
-      uint32_t bits = flag[w];
+      // (word w of the flag bitmap: lane w & 63 of its chunk of 64 words holds it)
+      if (w >= 64 && (w & 63) == 0) flag0 = (w + lane < nflag) ? flag[w + lane] : 0u;
+      uint32_t bits = lane_u32(flag0, w & 63);
       while (bits && st == T_OK) {
         const uint32_t b = (uint32_t)__ffs((int)bits) - 1;
         bits &= bits - 1;
@@ -628,6 +707,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             KM_DFS_STAMP(3);                               // directory word, home pair, request                               // thresholds + key and request of the next lookup
 #ifdef KM_DFS_STAMPS
             ++dfs_steps;
+            ++dfs_general;
 #endif
           }
           // ---- chain run.  cur has exactly one child left to take.  As long as that keeps
@@ -651,86 +731,92 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             uint32_t c = (uint32_t)__ffs((int)mask) - 1;   // its one child left, and that child's count
             uint32_t cnt = pick4(c4, c);
             bool expanded = false;                         // (c4, mask) = a finished expansion of x
-            ChainKey ck;
-            chain_key_init(tab, &ck, x & tab.pmask);       // of x's own group: every child's follows from it
-            BucketLanes bl;
-            bl.valid = false; bl.resident = false; bl.bucket = 0; bl.S = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) { bl.tag[i] = EMPTY; bl.zw[i] = 0; }
-            const uint32_t lane3 = lane & 3u;
+            // State of a step: x has exactly the child c (count cnt) left to take; child = x[1:] + c;
+            // T = tag of the group of child[1:] (what the expansion of child looks up); hint: child
+            // sits in its home slot of the node set, i.e. is most likely a rejoin — stop there and
+            // let the general step decide (only a hint: misses are caught by the booking below).
+            // From the second step on all of it comes precomputed out of the slot that named the
+            // child (device_common.h: BucketLanes); only the first step works it out here.
+            uint64_t child = ((x << 2) | c) & tab.kmask;
+            auto slow_state = [&](uint64_t ch, uint64_t* T_out, bool* hint_out) {
+              const uint64_t P = ch & tab.pmask;
+              uint32_t flip_;
+              *T_out = group_tag(tab, P, revcomp(P, k - 1), &flip_);
+              const uint64_t at_home = keys[set_home(ch, cap)];
+              *hint_out = __builtin_amdgcn_readfirstlane((int)(at_home == ch)) != 0;
+            };
+            uint64_t T;
+            bool hint;
+            slow_state(child, &T, &hint);
             while (n < room) {
-              const uint64_t child = ((x << 2) | c) & tab.kmask;
-              // a child that sits in its home slot of the node set is (most likely) a rejoin:
-              // stop here and let the general step decide.  Only a hint — misses are caught below.
-              const uint64_t at_home = keys[set_home(child, cap)];
-              // the child's group: its key state follows from the last one, its bucket is (mostly)
-              // the one the lanes already hold (device_common.h: BucketLanes)
-              const uint64_t P = child & tab.pmask;
-              chain_key_step(tab, &ck, P, c);
-              uint32_t flip;
-              const uint64_t tag = group_tag(tab, P, ck.R, &flip);
-              KM_DFS_STAMP(9);
-              if (!bl.valid || bl.bucket != ck.bucket) {
-                bucket_load_wave(tab, ck.bucket, &bl, &fetch_u);
-#ifdef KM_DFS_STAMPS
-                ++dfs_loads;
-                if (bl.S > dfs_maxS) dfs_maxS = bl.S;
-#endif
-              }
-#ifdef KM_DFS_STAMPS
-              if (!bl.resident) ++dfs_nonres;
-#endif
-              KM_DFS_STAMP(3);
-#ifdef KM_DFS_STAMPS_CALIBRATE
-              KM_DFS_STAMP(4);                             // back to back: the cost of a stamp itself ("unwind")
-#endif
-              if (at_home == child) break;
+              if (hint) break;
               if (lane == n) { rkey = child; rcnt = cnt; }
               ++n;
               x = child;
-              // ---- the expansion of child: its group's two count words out of the bucket the
-              // lanes hold (no count escaped); the four thresholds are one compare on four lanes
-              uint64_t zw = 0;
-              bool packed_ok = bl.resident;
-              if (packed_ok) zw = bucket_find_wave(bl, tag);
-              uint32_t cl = 0, xm = 0;
-              const uint32_t flip3 = flip ? 3u : 0u;
-              if (packed_ok) {
-                cl = (uint32_t)(zw >> ((lane3 ^ flip3) << 4)) & 0xFFFFu;   // lane i < 4: count of child base i
-                packed_ok = (__ballot(cl == COUNT_ESCAPE) & 0xFull) == 0;
-              }
-              KM_DFS_STAMP(2);
-              if (packed_ok) {
-                const uint32_t z = (uint32_t)zw, w = (uint32_t)(zw >> 32);
-                const uint64_t sum = (uint64_t)((z & 0xFFFFu) + (z >> 16) + (w & 0xFFFFu) + (w >> 16));
-                uint32_t T = a.thr_T;
-                if (sum >= a.thr_below) {
-                  bool none;
-                  T = child_threshold(sum, a.ratio, a.n_cutoff, &none);   // none: T above every u16
+              KM_DFS_STAMP(0);
+              // ---- the expansion of x: its group among the slots the lanes hold
+              SlotHit h;
+              h.hit = false; h.info = 0; h.ntag = EMPTY;
+              if (bl.valid && bl.resident) h = bucket_find_wave(bl, T);
+#ifdef KM_DFS_STAMPS
+              if (h.hit) asm volatile("" :: "s"(h.info));
+#endif
+              KM_DFS_STAMP(10);                            // chain: the tag among the lanes
+              bool general = false;                        // (c4) holds the expansion of x from a general lookup
+              if (!h.hit) {
+                // not among the lanes: the group lives in another bucket (the minimizer changed), in a
+                // bucket too large for the lanes, or does not exist.  Its key is worked out once: the
+                // directory word of its bucket (kept in dcache) and, already on its way, its home pair.
+                PendingLookup p;
+                children_issue_wave(tab, x, &dcache, &p);
+                if (!bl.valid || p.g.bucket != bl.bucket) {
+                  bucket_load_wave(tab, rule, p.g.bucket, dcache.lo, dcache.hi, keys, cap, &bl, &fetch_u);
+#ifdef KM_DFS_STAMPS
+                  ++dfs_loads;
+                  if (bl.S > dfs_maxS) dfs_maxS = bl.S;
+#endif
+                  if (bl.resident) h = bucket_find_wave(bl, T);
+#ifdef KM_DFS_STAMPS
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                  KM_DFS_STAMP(11);                        // chain: another bucket (key, directory word, slots, successors)
                 }
-                xm = (uint32_t)(__ballot(cl >= T) & 0xFull);
-                KM_DFS_STAMP(8);
-                if (xm != 0 && (xm & (xm - 1)) == 0) {
-                  c = (uint32_t)__ffs((int)xm) - 1;
-                  cnt = (uint32_t)(zw >> ((c ^ flip3) << 4)) & 0xFFFFu;
+                if (!h.hit) {
+#ifdef KM_DFS_STAMPS
+                  if (!bl.resident) ++dfs_nonres;
+#endif
+                  c4 = children_finish_wave(tab, p, &fetch_u);   // (all zero if the group does not exist)
+                  general = true;
+                  KM_DFS_STAMP(12);                        // chain: lookup in a bucket too large for the lanes
+                }
+              }
+              if (!general) {
+                if (h.info & SLOT_SINGLE) {
+                  c = h.info & 3u;
+                  cnt = h.info >> 16;
+                  hint = (h.info & SLOT_HINT) != 0;
+                  T = h.ntag;
+                  child = ((x << 2) | c) & tab.kmask;
                   continue;
                 }
-                c4 = make_uint4((uint32_t)(zw >> ((0u ^ flip3) << 4)) & 0xFFFFu, (uint32_t)(zw >> ((1u ^ flip3) << 4)) & 0xFFFFu,
-                                (uint32_t)(zw >> ((2u ^ flip3) << 4)) & 0xFFFFu, (uint32_t)(zw >> ((3u ^ flip3) << 4)) & 0xFFFFu);
-              } else {
-                // a bucket too large for the lanes, or an escaped count: the general lookup
+                // none, several, or an escaped count: the run ends here (or nearly); the counts
+                // themselves are not kept in the lanes
                 c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
-                xm = child_mask(c4, a.ratio, a.n_cutoff);
-                KM_DFS_STAMP(8);
+              }
+              {
+                const uint32_t xm = child_mask(c4, a.ratio, a.n_cutoff);
+                KM_DFS_STAMP(13);                          // chain: full expansion
                 if (xm != 0 && (xm & (xm - 1)) == 0) {
                   c = (uint32_t)__ffs((int)xm) - 1;
                   cnt = pick4(c4, c);
+                  child = ((x << 2) | c) & tab.kmask;
+                  slow_state(child, &T, &hint);
                   continue;
                 }
+                mask = xm;
+                expanded = true;
+                break;
               }
-              mask = xm;
-              expanded = true;
-              break;
             }
             if (!expanded) {
               // x still has its one child c to take (no room left, or the hint): all the general
@@ -743,6 +829,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               steps += n;
 #ifdef KM_DFS_STAMPS
               dfs_steps += n;
+              ++dfs_runs;
 #endif
               // ---- booking: first child of the run that is already a node or on the stack
               const bool act = lane < n;
@@ -918,12 +1005,12 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   if (a.stamps && lane == 0) {
     unsigned long long tend;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
-    unsigned long long* o = a.stamps + 16ull * blockIdx.x;
-    for (int q = 0; q < 8; ++q) o[q] = dfs_acc[q];
-    o[8] = dfs_steps; o[9] = (uint32_t)tend - dfs_t0; o[10] = t; o[11] = probes_u;
-    o[12] = dfs_acc[8]; o[13] = dfs_acc[9];
-    o[14] = (unsigned long long)dfs_loads | ((unsigned long long)dfs_nonres << 20) | ((unsigned long long)dfs_maxS << 40);
-    o[15] = 0x6466735f7374616dull;                         // record marker
+    unsigned long long* o = a.stamps + 32ull * blockIdx.x;
+    for (int q = 0; q < 16; ++q) o[q] = dfs_acc[q];
+    o[16] = dfs_steps; o[17] = (uint32_t)tend - dfs_t0; o[18] = t; o[19] = probes_u;
+    o[20] = dfs_loads; o[21] = dfs_nonres; o[22] = dfs_maxS; o[23] = dfs_general; o[24] = dfs_runs;
+    o[25] = dfs_t_setup - dfs_t0; o[26] = n_nodes - n_ref;
+    o[31] = 0x6466735f7374616dull;                         // record marker
   }
 #endif
   if (lane == 0) {

@@ -36,29 +36,33 @@ flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
 for _ in range(3):
     b.run(flags, st)
     b.sync()
-rec = b.debug_stamps()
-rec = rec[rec[:, 15] == 0x6466735F7374616D]
-names = ["other", "late request", "wait+resolve", "dir+pair request", "unwind", "set probe", "rejoin", "push",
-         "thresholds", "next key"]
-rec = np.concatenate([rec[:, :12], rec[:, 12:14], rec[:, 14:]], axis=1)
-SEC = [0, 1, 2, 3, 4, 5, 6, 7, 12, 13]
-tot = rec[:, 9].astype(np.float64)
+rec = b.debug_stamps().reshape(-1, 32)
+rec = rec[rec[:, 31] == 0x6466735F7374616D]
+names = ["other", "late request", "wait+resolve", "next request", "unwind", "set probe", "rejoin", "push/booking",
+         "thresholds", "next key", "chain: find", "chain: bucket change", "chain: non-resident lookup",
+         "chain: end expansion", "-", "-"]
+tot = rec[:, 17].astype(np.float64)
+setup = rec[:, 25].astype(np.float64)
 order = np.argsort(-tot)
-print("%d k_dfs waves; shader-clock ticks; longest five:" % len(rec))
-for i in order[:5]:
+print("%d k_dfs waves; shader-clock ticks; longest eight:" % len(rec))
+for i in order[:8]:
     r = rec[i]
-    sec = r[SEC].astype(np.float64)
-    print("  target %5d: %7d ticks, %3d expansions (%5.0f ticks each), %4d probes, setup+tail %4.1f %%: " %
-          (r[10], r[9], r[8], sec.sum() / max(1, r[8]), r[11], 100 * (1 - sec.sum() / r[9])) +
-          ", ".join("%s %.0f%%" % (nm, 100 * v / sec.sum()) for nm, v in zip(names, sec) if v))
-extra = rec[:, 14]
-loads, nonres, maxS = extra & 0xFFFFF, (extra >> 20) & 0xFFFFF, extra >> 40
+    sec = r[:16].astype(np.float64)
+    print("  target %5d: %7d ticks (setup %5d, unaccounted %5d), %3d steps of which %2d general, %d runs, %2d bucket "
+          "loads (largest %4d slots), %3d non-resident lookups, %3d new nodes:\n      " %
+          (r[18], r[17], r[25], r[17] - r[25] - sec.sum(), r[16], r[23], r[24], r[20], r[22], r[21], r[26]) +
+          ", ".join("%s %d" % (nm, v) for nm, v in zip(names, sec) if v))
 print("bucket loads %d, chain lookups in a bucket too large for the lanes %d, largest bucket %d slots; "
-      "loads per wave p50 %d max %d" % (loads.sum(), nonres.sum(), maxS.max(), np.median(loads), loads.max()))
-print("largest-bucket histogram (per wave):", np.bincount(np.minimum(maxS // 32, 16)).tolist())
-sec = rec[:, SEC].astype(np.float64).sum(axis=0)
-print("all waves: %.0f ticks per expansion; setup+tail %.1f %% of wave time; " %
-      (sec.sum() / rec[:, 8].sum(), 100 * (1 - sec.sum() / tot.sum())) +
-      ", ".join("%s %.0f%%" % (nm, 100 * v / sec.sum()) for nm, v in zip(names, sec)))
+      "loads per wave p50 %d max %d" % (rec[:, 20].sum(), rec[:, 21].sum(), rec[:, 22].max(), np.median(rec[:, 20]), rec[:, 20].max()))
+print("largest-bucket histogram (per wave, bins of 32 slots):", np.bincount(np.minimum(rec[:, 22] // 32, 16).astype(np.int64)).tolist())
+sec = rec[:, :16].astype(np.float64).sum(axis=0)
+print("all waves: wave time p50 %d p90 %d p99 %d max %d; setup p50 %d; per-section share: " %
+      (np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), np.median(setup)) +
+      ", ".join("%s %.0f%%" % (nm, 100 * v / sec.sum()) for nm, v in zip(names, sec) if v))
+per = {"chain: find": (10, rec[:, 16] - rec[:, 23]), "chain: bucket change": (11, rec[:, 20]), "chain: non-resident lookup": (12, rec[:, 21]),
+       "general step (1+2+3+8+9)": (None, rec[:, 23])}
+for nm, (ix, cnt) in per.items():
+    v = rec[:, ix].sum() if ix is not None else rec[:, [1, 2, 3, 8, 9]].sum()
+    print("  %s: %.0f ticks each (%d events)" % (nm, v / max(1, cnt.sum()), cnt.sum()))
 b.close()
 db.close()
