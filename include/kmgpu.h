@@ -271,6 +271,9 @@ void km_report_free(char* text, uint64_t* row_off, int32_t* err);
  * end), two s_memrealtime stamps (start, end) and the HW_ID placement, 16 words per wave.
  * dst == NULL only reports the size.  Stamped runs are slower; never use them for timing. */
 int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_words, uint64_t* n_words);
+/* Diagnostics: device counters of the last run — out4[0] flagged targets (k_seed), [1] unflagged targets
+ * the pure-chain pass handed to k_graph, [2] flagged targets the epilogue of k_dfs left to k_graph, [3] 0. */
+int km_batch_debug_counts(km_batch_t* b, uint32_t* out4);
 
 /* ---- misc ---------------------------------------------------------------- */
 const char* km_strerror(int code);

@@ -541,21 +541,28 @@ __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, 
 }
 // the slot of the group `tag` in a resident bucket
 struct SlotHit { uint64_t ntag; uint32_t info; bool hit; };
-__device__ inline SlotHit bucket_find_wave(const BucketLanes& b, uint64_t tag) {
-  SlotHit h;
-  h.hit = false; h.info = 0; h.ntag = EMPTY;
-#pragma unroll
-  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
-    if (!h.hit && 64u * i < b.S) {                   // wave-uniform
-      const unsigned long long hit_ = __ballot(b.tag[i] == tag);
+// (nested, so that a hit leaves through one branch: a flat loop over the sets makes the compiler chain
+// an exit flag through every later set — sixteen taken branches behind a hit in the first one)
+template <uint32_t I>
+__device__ inline void bucket_find_from(const BucketLanes& b, uint64_t tag, SlotHit& h) {
+  if constexpr (I < BUCKET_LANES_SETS) {
+    if (64u * I < b.S) {                             // wave-uniform
+      const unsigned long long hit_ = __ballot(b.tag[I] == tag);
       if (hit_) {
         const uint32_t l_ = (uint32_t)__ffsll((long long)hit_) - 1;
-        h.info = lane_u32(b.info[i], l_);
-        h.ntag = lane_u64(b.ntag[i], l_);
+        h.info = lane_u32(b.info[I], l_);
+        h.ntag = lane_u64(b.ntag[I], l_);
         h.hit = true;
+      } else {
+        bucket_find_from<I + 1>(b, tag, h);
       }
     }
   }
+}
+__device__ inline SlotHit bucket_find_wave(const BucketLanes& b, uint64_t tag) {
+  SlotHit h;
+  h.hit = false; h.info = 0; h.ntag = EMPTY;
+  bucket_find_from<0>(b, tag, h);
   return h;
 }
 // canonical tag of the group of the (k-1)-mer P (R = its reverse complement)
@@ -660,7 +667,7 @@ __device__ inline void slot_successor(const TableView& t, const ChildRule& r, ui
     if (R2 < P2) nt = (R2 << 1) | 1ull;
   }
   *ntag = nt;
-  const bool hint = keys[set_home(child, cap)] == child;
+  const bool hint = keys[set_home(child >> 2, cap)] == child;     // (the node set hashes by prefix: walk_kernel.h)
   *info = c | SLOT_SINGLE | (hint ? SLOT_HINT : 0u) | (cnt << 16);
 }
 

@@ -46,9 +46,6 @@
 namespace kmd {
 
 constexpr uint32_t GRAPH_THREADS = 256;
-constexpr uint32_t POOL_GROUPS = 64;       // bump-allocation counters, one 128-B line each
-constexpr uint32_t POOL_CTR_STRIDE = 16;   // uint64 per group
-constexpr uint32_t NOT_BARE = 0xFFFFFFFFu;
 
 struct GraphArgs {
   int k;
@@ -76,6 +73,10 @@ struct GraphArgs {
   // only, ablations): block b then takes target b.
   uint32_t* work_list;
   uint32_t* work_n;
+  // When the epilogue of k_dfs answers the regular flagged targets itself (walk_kernel.h), the first
+  // part of the list is `left` (work_n[2] entries: what it could not answer) instead of all flagged ones.
+  const uint32_t* left;
+  uint32_t dfs_answers;      // 1: this run's k_dfs had its epilogue on
   // outputs
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
   const uint64_t h_woff = a.woff[t];
-  if (tid == 0) a.t_refmax[t] = NOT_BARE;      // every target passes here before k_graph sees it
+  // (a flagged target's t_refmax belongs to k_dfs when its epilogue is on: it may be running right now)
+  if (tid == 0 && !(a.dfs_answers && h_tflag)) a.t_refmax[t] = NOT_BARE;
   if (h_status != T_OK) {
     if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
     return;
@@ -255,8 +257,10 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   if (BIG || a0.tids || !a0.work_list) {
     t_ = a0.tids ? a0.tids[blockIdx.x] : blockIdx.x;
   } else {
-    if (blockIdx.x >= a0.work_n[0] + a0.work_n[1]) return;
-    t_ = a0.work_list[blockIdx.x];
+    const uint32_t n_first = a0.dfs_answers ? a0.work_n[2] : a0.work_n[0];
+    if (blockIdx.x >= n_first + a0.work_n[1]) return;
+    t_ = blockIdx.x < n_first ? (a0.dfs_answers ? a0.left[blockIdx.x] : a0.work_list[blockIdx.x])
+                              : a0.work_list[a0.work_n[0] + (blockIdx.x - n_first)];
   }
   const uint32_t t = t_;
   GraphArgs a = a0;

@@ -648,6 +648,10 @@ struct km_batch {
   // k_seed work items and flag bitmaps
   DevBuf<uint32_t> d_item_off, d_flagbits, d_tflag, d_flagged, d_nflagged;
   DevBuf<uint4> d_flag_rec;            // k_seed -> k_dfs: one 32-byte record per flagged target
+  DevBuf<uint32_t> d_left;             // k_dfs -> k_graph: flagged targets the epilogue did not answer
+  DevBuf<EpiArgs> d_epi;               // where that epilogue writes (device copy of h_epi)
+  EpiArgs h_epi{};
+  bool epi_valid = false;
   DevBuf<unsigned long long> d_dfs_probes;
   DevBuf<uint64_t> d_items;
   DevBuf<uint64_t> d_fw_off;
@@ -764,7 +768,9 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_tflag.alloc(max_targets));
   A(b->d_flagged.alloc(max_targets));
   A(b->d_flag_rec.alloc(2ull * max_targets));
-  A(b->d_nflagged.alloc(2));
+  A(b->d_left.alloc(max_targets));
+  A(b->d_epi.alloc(1));
+  A(b->d_nflagged.alloc(4));
   A(b->d_dfs_probes.alloc(max_targets));
   A(b->d_node_base.alloc(max_targets));
   A(b->d_node_cap.alloc(max_targets));
@@ -837,7 +843,7 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   drop_graph(b);
   b->d_bases.release(); b->d_toff.release(); b->d_woff.release(); b->d_packed.release();
   b->d_items.release(); b->d_item_off.release(); b->d_flagbits.release(); b->d_fw_off.release();
-  b->d_tflag.release(); b->d_flagged.release(); b->d_flag_rec.release(); b->d_nflagged.release(); b->d_dfs_probes.release();
+  b->d_tflag.release(); b->d_flagged.release(); b->d_flag_rec.release(); b->d_left.release(); b->d_epi.release(); b->d_nflagged.release(); b->d_dfs_probes.release();
   b->d_node_base.release(); b->d_node_cap.release();
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
   b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release(); b->d_t_nruns.release(); b->d_t_refmax.release();
@@ -982,6 +988,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.flagged = b->d_flagged.p;
   a.flag_rec = b->d_flag_rec.p;
   a.fast_extra = FAST_EXTRA;
+  a.epi = nullptr;
   a.n_flagged = b->d_nflagged.p;
   a.list = b->d_flagged.p;
   a.n_list_dev = b->d_nflagged.p;
@@ -1009,6 +1016,8 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.tids = nullptr;
   g.work_list = b->d_flagged.p;
   g.work_n = b->d_nflagged.p;
+  g.left = b->d_left.p;
+  g.dfs_answers = 0;
   g.n_targets = b->n_targets;
   g.node_kmer = b->d_node_kmer.p;
   g.node_cnt = b->d_node_cnt.p;
@@ -1055,10 +1064,13 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
 // rest of its batch.
 static uint32_t words_cap_for(uint32_t len) { return round_up((len + 31) / 32 + 1, 2); }
 
+// slots of k_dfs's node set in the fast tier: load <= 0.55 with every allowed extra node in it
+static uint32_t walk_hs_cap(uint32_t nref) { return round_up((uint32_t)(((uint64_t)(nref + FAST_EXTRA) * 9 + 4) / 5), 64); }
+
 static bool fast_fits(const km_batch* b, uint32_t nref, uint32_t bcap) {
   const uint32_t len = nref + (uint32_t)b->db->k - 1;
   const uint32_t wc = words_cap_for(len);
-  const uint32_t hs = round_up(2 * (nref + FAST_EXTRA), 64);
+  const uint32_t hs = walk_hs_cap(nref);
   const uint32_t ncap = nref + FAST_EXTRA + 2, hcap = round_up(ncap + ncap / 2 + 1, 64);
   return walk_lds_bytes(hs, wc, bcap) <= FAST_LDS_LIMIT &&
          graph_ws_bytes<uint16_t>(ncap, hcap, wc) <= FAST_LDS_LIMIT && ncap < 0xFFFF &&
@@ -1081,7 +1093,7 @@ static void fast_geometry(km_batch* b) {
   const uint32_t len = nref + (uint32_t)k - 1;
   WalkArgs& wa = b->wa;
   fill_walk_args(b, wa);
-  wa.hs_cap = round_up(2 * (nref + FAST_EXTRA), 64);
+  wa.hs_cap = walk_hs_cap(nref);
   wa.words_cap = words_cap_for(len);
   wa.fcap = round_up(std::min<uint32_t>(b->p.max_stack, FAST_FCAP_MAX - 2) + 2, 2);
   wa.bcap = bcap;
@@ -1101,6 +1113,24 @@ static void fast_geometry(km_batch* b) {
     ga.hcap_pure = 64;
     b->pure_lds = 256 + ga.words_cap * 8;
   }
+  // the epilogue of k_dfs answers the regular flagged targets when the graph stage is wanted in full
+  // (KM_EPILOGUE=0: diagnostics, everything through k_graph as in round 2)
+  static const bool epilogue_on = !(getenv("KM_EPILOGUE") && atoi(getenv("KM_EPILOGUE")) == 0);
+  if (epilogue_on && b->graph_mode == 0 && ga.dbg == 0 && ga.work_list != nullptr) {
+    EpiArgs e;
+    memset(&e, 0, sizeof e);
+    e.counters = ga.counters; e.path_pool = ga.path_pool; e.run_pool = ga.run_pool;
+    e.p_target = ga.p_target; e.p_runbase = ga.p_runbase; e.p_nruns = ga.p_nruns; e.p_len = ga.p_len;
+    e.p_mincov = ga.p_mincov; e.r_start = ga.r_start; e.r_len = ga.r_len;
+    e.g_status = ga.g_status; e.t_npaths = ga.t_npaths; e.t_pathbase = ga.t_pathbase; e.t_nruns = ga.t_nruns;
+    e.t_refmax = ga.t_refmax;
+    e.left = b->d_left.p; e.n_left = b->d_nflagged.p + 2;
+    if (!b->epi_valid || memcmp(&e, &b->h_epi, sizeof e) != 0) {
+      if (hipMemcpy(b->d_epi.p, &e, sizeof e, hipMemcpyHostToDevice) == hipSuccess) { b->h_epi = e; b->epi_valid = true; }
+      else b->epi_valid = false;
+    }
+    if (b->epi_valid) { wa.epi = b->d_epi.p; ga.dfs_answers = 1; }
+  }
 }
 
 // LDS-tier graph kernels, instantiated for k = 31 where that is the database's k
@@ -1117,6 +1147,7 @@ static void launch_graph(km_batch* b, hipStream_t st, const GraphArgs& ga) {
 static int launch_graph_fast(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemsetAsync(b->d_counters.p, 0, (POOL_GROUPS * POOL_CTR_STRIDE + 16) * sizeof(unsigned long long), st));
   b->ga.use_need_full = 1;
+  b->ga.dfs_answers = 0;                  // no k_dfs in this pass: every flagged target goes through k_graph
   HIPCHK(hipMemsetAsync(b->d_nflagged.p + 1, 0, sizeof(uint32_t), st));   // k_graph_pure appends its hand-overs again
   launch_pure(b, st, b->ga);
   launch_graph(b, st, b->ga);
@@ -1738,6 +1769,16 @@ extern "C" int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_
   if (!dst || !n) return KM_OK;
   if (cap_words < n) return fail(KM_E_CAPACITY, "stamp buffer too small");
   HIPCHK(hipMemcpy(dst, b->d_stamps.p, n * 8, hipMemcpyDeviceToHost));
+  return KM_OK;
+}
+
+// Diagnostics: the device counters of the last run — [0] flagged targets (k_seed), [1] unflagged
+// targets k_graph_pure handed to k_graph, [2] flagged targets the epilogue of k_dfs left to k_graph.
+extern "C" int km_batch_debug_counts(km_batch_t* b, uint32_t* out4) {
+  if (!b || !out4) return fail(KM_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipMemcpy(out4, b->d_nflagged.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return KM_OK;
 }
 

@@ -44,10 +44,43 @@
 namespace kmd {
 
 constexpr uint32_t ST_NODE = 1, ST_ONSTACK = 2, ST_POPPED = 3;
+// One 16-bit word per slot of k_dfs's node set: the state above in its two top bits and, for a node,
+// its index (node i = i-th target k-mer, then registration order) — what the epilogue of k_dfs needs
+// to read the graph's shape off the set.  (The large tier never looks at the index.)
+__device__ inline uint16_t slot_meta(uint32_t state, uint32_t idx) { return (uint16_t)((state << 14) | (idx & 0x3FFFu)); }
+__device__ inline uint32_t meta_state(uint16_t m) { return (uint32_t)m >> 14; }
+__device__ inline uint32_t meta_index(uint16_t m) { return (uint32_t)m & 0x3FFFu; }
 constexpr uint32_t T_OK = 0, T_NODE_LIMIT = 1, T_REPEAT = 2, T_EMPTY = 3, T_BAD_BASE = 4,
                    T_INTERNAL = 5, T_NEEDS_BIG = 100;
 constexpr uint64_t DFS_STEP_LIMIT = 1ull << 32;
 constexpr uint32_t SEED_BLOCK = 256;     // seeds per k_seed work item
+
+constexpr uint32_t POOL_GROUPS = 64;       // path / run pools: bump-allocation counters, one 128-B line each
+constexpr uint32_t POOL_CTR_STRIDE = 16;   // uint64 per group
+constexpr uint32_t NOT_BARE = 0xFFFFFFFFu;
+
+// What the epilogue of k_dfs writes (graph_kernel.h has the meaning of every array): kept in device
+// memory and read once per wave, so that it costs k_dfs no registers while it walks.
+struct EpiArgs {
+  unsigned long long* counters;
+  uint64_t path_pool, run_pool;
+  uint32_t* p_target;
+  uint64_t* p_runbase;
+  uint32_t* p_nruns;
+  uint32_t* p_len;
+  uint32_t* p_mincov;
+  uint32_t* r_start;
+  uint32_t* r_len;
+  uint32_t* g_status;
+  uint32_t* t_npaths;
+  uint32_t* t_pathbase;
+  uint32_t* t_nruns;
+  uint32_t* t_refmax;
+  uint32_t* left;         // flagged targets the epilogue did not answer: k_graph's work list
+  uint32_t* n_left;       // device counter
+};
+constexpr uint32_t EPI_CHUNKS = 3;         // walk-discovered nodes the epilogue looks at: up to 192 (fast tier: 160)
+constexpr uint32_t EPI_MAX_BUBBLES = 8;    // more than that: left to k_graph
 
 struct __attribute__((aligned(16))) BranchFrame {
   uint4 c4;
@@ -84,6 +117,7 @@ struct WalkArgs {
   // offset, packed-word offset, 0, 0}
   uint4* flag_rec;
   uint32_t fast_extra;        // fast tier: a target's node storage holds n_ref + fast_extra nodes
+  const EpiArgs* epi;         // fast tier: where the epilogue delivers paths (null: no epilogue, no list)
   // k_dfs target selection: list + count (device counter or host value)
   const uint32_t* list;
   const uint32_t* n_list_dev;
@@ -124,7 +158,7 @@ __host__ __device__ inline uint64_t walk_lds_bytes(uint32_t hs_cap, uint32_t wor
   b += (uint64_t)hs_cap * 8;       // keys
   b += (uint64_t)words_cap * 8;    // packed target
   b += (uint64_t)bcap * 32;        // branch frames
-  b += (uint64_t)hs_cap;           // slot states
+  b += (uint64_t)hs_cap * 2;       // slot states + node indices (slot_meta)
   return (b + 15) & ~15ull;
 }
 __host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t words_cap,
@@ -144,8 +178,11 @@ __device__ inline uint32_t set_home(uint64_t key, uint32_t cap) {
 
 // Per-lane insert (distinct lanes may insert concurrently).  Returns the slot;
 // *was_new tells whether this call created the entry.
+// SH = 2 (k_dfs's node set): the home slot follows from the k-mer's (k-1)-mer PREFIX, so that the k-mers
+// sharing a prefix share one probe sequence — who shares a prefix is then read off one cluster.
+template <int SH = 0>
 __device__ inline int set_insert_lane(uint64_t* keys, uint32_t cap, uint64_t key, bool* was_new) {
-  uint32_t s = set_home(key, cap);
+  uint32_t s = set_home(key >> SH, cap);
   for (uint32_t step = 0; step < cap; ++step) {
     unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[s]),
                                        (unsigned long long)EMPTY, (unsigned long long)key);
@@ -159,8 +196,9 @@ __device__ inline int set_insert_lane(uint64_t* keys, uint32_t cap, uint64_t key
 
 // Per-lane lookup (every lane its own key, no writers meanwhile): the slot of the key (*found)
 // or the empty slot that ends its probe sequence; -1 if the set is full of other keys.
+template <int SH = 0>
 __device__ inline int set_lookup_lane(const uint64_t* keys, uint32_t cap, uint64_t key, bool* found) {
-  uint32_t s = set_home(key, cap);
+  uint32_t s = set_home(key >> SH, cap);
   for (uint32_t step = 0; step < cap; ++step) {
     const uint64_t kv = keys[s];
     if (kv == key) { *found = true; return (int)s; }
@@ -173,9 +211,10 @@ __device__ inline int set_lookup_lane(const uint64_t* keys, uint32_t cap, uint64
 
 // Wave-cooperative lookup (all 64 lanes call with the same key).  Returns the
 // slot of the key (*found) or the empty slot where it would be inserted.
+template <int SH = 0>
 __device__ inline int set_find(const uint64_t* keys, uint32_t cap, uint64_t key, bool* found) {
   const uint32_t lane = (uint32_t)lane_id();
-  uint32_t base = set_home(key, cap);
+  uint32_t base = set_home(key >> SH, cap);
   for (uint32_t scanned = 0; scanned < cap + 64; scanned += 64) {
     uint32_t s = base + lane;
     if (s >= cap) s -= cap;
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
     a.dfs_probes[t] = 0;
     a.fetches[t] = 0;
     a.tflag[t] = 0;
-    if (t == 0) { a.n_flagged[0] = 0; a.n_flagged[1] = 0; }      // [1]: targets k_graph_pure hands to k_graph
+    if (t == 0) { a.n_flagged[0] = 0; a.n_flagged[1] = 0; a.n_flagged[2] = 0; }   // [1]: targets k_graph_pure hands to k_graph, [2]: those k_dfs's epilogue leaves to it
   }
 }
 
@@ -493,6 +532,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
     dfs_acc[n] += (uint32_t)t_ - dfs_prev;                                                    \
     dfs_prev = (uint32_t)t_;                                                                  \
+    ++dfs_nstamps;                                                                            \
   } while (0)
 #else
 #define KM_DFS_STAMP(n) do {} while (0)
@@ -503,6 +543,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef KM_DFS_STAMPS
   uint32_t dfs_entry;
+  const unsigned long long dfs_real0 = __builtin_amdgcn_s_memrealtime();
   {
     unsigned long long t_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
@@ -510,6 +551,11 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   }
 #endif
   const uint32_t lane = (uint32_t)lane_id();
+#ifndef KM_DFS_STAMPS
+  // diagnostics (KM_SEED_STAMPS in the environment): when this wave started and ended, 100 MHz clock
+  unsigned long long life0 = 0, life1 = 0, life2 = 0, lifeB = 0, lifeC = 0;
+  if (a.stamps) life0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const TableView tab = specialized_view<K>(a.tab);
   const int k = tab.k;
   // the target: fast tier — entry blockIdx.x of k_seed's list of flagged targets, with what the
@@ -549,7 +595,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   uint64_t* keys = reinterpret_cast<uint64_t*>(wsb);
   uint64_t* words = keys + cap;
   BranchFrame* bf = reinterpret_cast<BranchFrame*>(words + a.words_cap);
-  uint8_t* state = reinterpret_cast<uint8_t*>(bf + a.bcap);
+  uint16_t* state = reinterpret_cast<uint16_t*>(bf + a.bcap);
   uint64_t* fk = reinterpret_cast<uint64_t*>(fwb);
   uint32_t* fc = reinterpret_cast<uint32_t*>(fk + a.fcap);
   uint32_t* fs = fc + a.fcap;
@@ -578,6 +624,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   uint32_t flag0 = 0;
   if (lane < nflag) flag0 = flag[lane];
   for (uint32_t w = lane; w <= nwords; w += 64) words[w] = a.packed[wo + w];
+  __syncthreads();                                           // the packed words
+#ifndef KM_DFS_STAMPS
+  if (a.stamps) lifeB = __builtin_amdgcn_s_memrealtime();
+#endif
   if constexpr (BIG) {
     for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
   } else {
@@ -586,7 +636,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     uint4* kq = reinterpret_cast<uint4*>(keys);
     for (uint32_t s = lane; s < cap / 2; s += 64) kq[s] = ones;
     uint4* sq = reinterpret_cast<uint4*>(state);
-    for (uint32_t s = lane; s < cap / 16; s += 64) sq[s] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t s = lane; s < cap / 8; s += 64) sq[s] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
   auto kmer_at = [&](uint32_t i) -> uint64_t {
@@ -595,38 +645,87 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
     return x >> (64 - 2 * k);
   };
+#ifndef KM_DFS_STAMPS
+  if (a.stamps) lifeC = __builtin_amdgcn_s_memrealtime();
+#endif
   uint32_t dup = 0;
+  // (R1) of the epilogue below — no two of the target's k-mers share their (k-1)-mer prefix, and the
+  // last one's suffix is nobody's prefix — is read off this very build: the set hashes a k-mer by its
+  // prefix, so k-mers sharing one follow the same probe sequence and the later one meets the earlier.
+  uint32_t shared = 0;
   // four k-mers per lane and round: their first compare-and-swaps are in flight together (an LDS
   // atomic returns after ~130 cycles; one after the other they were a quarter of the kernel's
   // fixed cost); the few that find their home slot taken probe on afterwards
-  for (uint32_t i0 = lane; i0 < n_ref; i0 += 256) {
-    uint64_t kk[4];
-    uint32_t hs[4];
-    unsigned long long old[4];
+  {
+    uint64_t pend_k[4];
+    uint32_t pend_sl[4], pend_i[4], n_pend = 0;
+    for (uint32_t i0 = lane; i0 < n_ref; i0 += 256) {
+      uint64_t kk[4];
+      uint32_t hs[4];
+      unsigned long long old[4];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      const uint32_t i = i0 + 64 * u;
-      kk[u] = i < n_ref ? kmer_at(i) : 0;
-      hs[u] = set_home(kk[u], cap);
-    }
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + 64 * u;
+        kk[u] = i < n_ref ? kmer_at(i) : 0;
+        hs[u] = set_home(kk[u] >> 2, cap);
+      }
 #pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      old[u] = EMPTY;
-      if (i0 + 64 * u < n_ref)
-        old[u] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[hs[u]]), (unsigned long long)EMPTY, (unsigned long long)kk[u]);
-    }
+      for (uint32_t u = 0; u < 4; ++u) {
+        old[u] = EMPTY;
+        if (i0 + 64 * u < n_ref) {
+          old[u] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[hs[u]]), (unsigned long long)EMPTY, (unsigned long long)kk[u]);
+        }
+      }
 #pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      if (i0 + 64 * u >= n_ref) continue;
-      if (old[u] == EMPTY) { state[hs[u]] = (uint8_t)ST_NODE; continue; }
-      if (old[u] == kk[u]) { dup = 1; continue; }
-      bool was_new;
-      const int s = set_insert_lane(keys, cap, kk[u], &was_new);
-      if (s >= 0 && was_new) state[s] = (uint8_t)ST_NODE;
-      if (s < 0 || !was_new) dup = 1;
+      for (uint32_t u = 0; u < 4; ++u) {
+        if (i0 + 64 * u >= n_ref) continue;
+        if (old[u] == EMPTY) { state[hs[u]] = slot_meta(ST_NODE, i0 + 64 * u); continue; }
+        if (old[u] == kk[u]) { dup = 1; continue; }
+        if ((old[u] >> 2) == (kk[u] >> 2)) shared = 1;
+#pragma unroll
+        for (uint32_t v = 0; v < 4; ++v) if (v == n_pend) { pend_k[v] = kk[u]; pend_sl[v] = hs[u]; pend_i[v] = i0 + 64 * u; }
+        ++n_pend;
+      }
+      // one retry loop for everything that found its home slot taken (see the fingerprint phase)
+      uint32_t guard = 0;
+      while (__any((int)(n_pend != 0))) {
+        if (++guard > 4 * cap) { dup = 1; break; }          // cannot happen (the set is at most 3/4 full)
+        if (n_pend) {
+          uint32_t sl = pend_sl[0] + 1;
+          if (sl == cap) sl = 0;
+          const unsigned long long o2 = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)EMPTY,
+                                                  (unsigned long long)pend_k[0]);
+          if (o2 != EMPTY && o2 != pend_k[0] && (o2 >> 2) == (pend_k[0] >> 2)) shared = 1;
+          if (o2 == EMPTY || o2 == pend_k[0]) {
+            if (o2 == EMPTY) state[sl] = slot_meta(ST_NODE, pend_i[0]);
+            else dup = 1;
+            --n_pend;
+#pragma unroll
+            for (uint32_t u = 0; u < 3; ++u) { pend_k[u] = pend_k[u + 1]; pend_sl[u] = pend_sl[u + 1]; pend_i[u] = pend_i[u + 1]; }
+          } else {
+            pend_sl[0] = sl;
+          }
+        }
+      }
     }
   }
   __syncthreads();
+  bool ref_pure = false;
+  if constexpr (!BIG) {
+    if (a.epi != nullptr && n_ref >= 2) {
+      if (lane == 0) {                                       // whoever has the last suffix as its prefix sits in its cluster
+        const uint64_t S = kmer_at(n_ref - 1) & tab.pmask;
+        uint32_t sl = set_home(S, cap);
+        for (uint32_t step = 0; step < cap; ++step) {
+          const uint64_t kv = keys[sl];
+          if (kv == EMPTY) break;
+          if ((kv >> 2) == S) { shared = 1; break; }
+          if (++sl == cap) sl = 0;
+        }
+      }
+      ref_pure = !__any((int)shared);
+    }
+  }
 
   uint32_t st = T_OK;
   uint32_t n_nodes = n_ref;
@@ -645,7 +744,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   if (__any((int)dup)) st = T_REPEAT;
 #ifdef KM_DFS_STAMPS
   uint32_t dfs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dfs_prev, dfs_t0, dfs_steps = 0;   // 32 bits: few SGPRs
-  uint32_t dfs_general = 0, dfs_runs = 0;
+  uint32_t dfs_general = 0, dfs_runs = 0, dfs_nstamps = 0;
   uint32_t dfs_loads = 0, dfs_nonres = 0, dfs_maxS = 0, dfs_t_setup;
   dfs_t0 = dfs_entry;
   {
@@ -655,6 +754,9 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   }
 #endif
 
+#ifndef KM_DFS_STAMPS
+  if (a.stamps) life1 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- exact DFS from every flagged seed, in target order ----------------------------
   if (st == T_OK) {
     uint32_t set_count = n_ref;
@@ -670,7 +772,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         const uint32_t i = w * 32 + b;
         uint64_t cur = kmer_at(i);
         bool fnd;
-        const int sslot = set_find(keys, cap, cur, &fnd);
+        const int sslot = set_find<2>(keys, cap, cur, &fnd);
         if (lane == 0) { fk[0] = cur; fc[0] = 0; fs[0] = (uint32_t)sslot; }
         uint32_t depth = 1, reg = 1, bsp = 0, parent_brk = 0, mask = 0, brk = 0;
         uint4 c4 = make_uint4(0, 0, 0, 0);
@@ -742,81 +844,100 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               const uint64_t P = ch & tab.pmask;
               uint32_t flip_;
               *T_out = group_tag(tab, P, revcomp(P, k - 1), &flip_);
-              const uint64_t at_home = keys[set_home(ch, cap)];
+              const uint64_t at_home = keys[set_home(ch >> 2, cap)];
               *hint_out = __builtin_amdgcn_readfirstlane((int)(at_home == ch)) != 0;
             };
             uint64_t T;
             bool hint;
             slow_state(child, &T, &hint);
-            while (n < room) {
-              if (hint) break;
-              if (lane == n) { rkey = child; rcnt = cnt; }
-              ++n;
-              x = child;
-              KM_DFS_STAMP(0);
-              // ---- the expansion of x: its group among the slots the lanes hold
-              SlotHit h;
-              h.hit = false; h.info = 0; h.ntag = EMPTY;
-              if (bl.valid && bl.resident) h = bucket_find_wave(bl, T);
-#ifdef KM_DFS_STAMPS
-              if (h.hit) asm volatile("" :: "s"(h.info));
-#endif
-              KM_DFS_STAMP(10);                            // chain: the tag among the lanes
-              bool general = false;                        // (c4) holds the expansion of x from a general lookup
-              if (!h.hit) {
+            // the rest of a step — the tag is not among the lanes, or its slot does not name a single
+            // child — kept out of the loop's hot path; true: the run goes on, false: (c4, mask) hold the
+            // expansion of x and the run ends
+            auto step_slow = [&](bool was_hit) -> bool {
+              if (!was_hit) {
                 // not among the lanes: the group lives in another bucket (the minimizer changed), in a
                 // bucket too large for the lanes, or does not exist.  Its key is worked out once: the
                 // directory word of its bucket (kept in dcache) and, already on its way, its home pair.
                 PendingLookup p;
                 children_issue_wave(tab, x, &dcache, &p);
+                SlotHit h2;
+                h2.hit = false; h2.info = 0; h2.ntag = EMPTY;
                 if (!bl.valid || p.g.bucket != bl.bucket) {
                   bucket_load_wave(tab, rule, p.g.bucket, dcache.lo, dcache.hi, keys, cap, &bl, &fetch_u);
 #ifdef KM_DFS_STAMPS
                   ++dfs_loads;
                   if (bl.S > dfs_maxS) dfs_maxS = bl.S;
 #endif
-                  if (bl.resident) h = bucket_find_wave(bl, T);
+                  if (bl.resident) h2 = bucket_find_wave(bl, T);
 #ifdef KM_DFS_STAMPS
                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                   KM_DFS_STAMP(11);                        // chain: another bucket (key, directory word, slots, successors)
                 }
-                if (!h.hit) {
+                if (h2.info & SLOT_SINGLE) {
+                  c = h2.info & 3u;
+                  cnt = h2.info >> 16;
+                  hint = (h2.info & SLOT_HINT) != 0;
+                  T = h2.ntag;
+                  child = ((x << 2) | c) & tab.kmask;
+                  return true;
+                }
+                if (!h2.hit) {
 #ifdef KM_DFS_STAMPS
                   if (!bl.resident) ++dfs_nonres;
 #endif
                   c4 = children_finish_wave(tab, p, &fetch_u);   // (all zero if the group does not exist)
-                  general = true;
                   KM_DFS_STAMP(12);                        // chain: lookup in a bucket too large for the lanes
+                } else {
+                  c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
                 }
-              }
-              if (!general) {
-                if (h.info & SLOT_SINGLE) {
-                  c = h.info & 3u;
-                  cnt = h.info >> 16;
-                  hint = (h.info & SLOT_HINT) != 0;
-                  T = h.ntag;
-                  child = ((x << 2) | c) & tab.kmask;
-                  continue;
-                }
+              } else {
                 // none, several, or an escaped count: the run ends here (or nearly); the counts
                 // themselves are not kept in the lanes
                 c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
               }
-              {
-                const uint32_t xm = child_mask(c4, a.ratio, a.n_cutoff);
-                KM_DFS_STAMP(13);                          // chain: full expansion
-                if (xm != 0 && (xm & (xm - 1)) == 0) {
-                  c = (uint32_t)__ffs((int)xm) - 1;
-                  cnt = pick4(c4, c);
-                  child = ((x << 2) | c) & tab.kmask;
-                  slow_state(child, &T, &hint);
-                  continue;
-                }
-                mask = xm;
-                expanded = true;
-                break;
+              const uint32_t xm = child_mask(c4, a.ratio, a.n_cutoff);
+              KM_DFS_STAMP(13);                            // chain: full expansion
+              if (xm != 0 && (xm & (xm - 1)) == 0) {
+                c = (uint32_t)__ffs((int)xm) - 1;
+                cnt = pick4(c4, c);
+                child = ((x << 2) | c) & tab.kmask;
+                slow_state(child, &T, &hint);
+                return true;
               }
+              mask = xm;
+              expanded = true;
+              return false;
+            };
+            // Two loops: the inner one only takes steps the lanes answer — it never writes the bucket
+            // the lanes hold, so those registers are loop-invariant there (with the bucket change inside
+            // the same loop the compiler copied all of them on every step); the outer one runs once per
+            // bucket change or other slow step.
+            for (;;) {
+              bool was_hit = false, stop = false;
+              for (;;) {
+                if (n >= room || hint) { stop = true; break; }
+                if (lane == n) { rkey = child; rcnt = cnt; }
+                ++n;
+                x = child;
+                KM_DFS_STAMP(0);
+                // ---- the expansion of x: its group among the slots the lanes hold
+                SlotHit h;
+                h.hit = false; h.info = 0; h.ntag = EMPTY;
+                if (bl.resident) h = bucket_find_wave(bl, T);   // (resident implies valid)
+#ifdef KM_DFS_STAMPS
+                if (h.hit) asm volatile("" :: "s"(h.info));
+#endif
+                KM_DFS_STAMP(10);                          // chain: the tag among the lanes
+                if (!(h.info & SLOT_SINGLE)) { was_hit = h.hit; break; }   // (info is 0 on a miss)
+                c = h.info & 3u;
+                cnt = h.info >> 16;
+                hint = (h.info & SLOT_HINT) != 0;
+                T = h.ntag;
+                child = ((x << 2) | c) & tab.kmask;
+              }
+              if (stop) break;
+              if (!step_slow(was_hit)) break;
             }
             if (!expanded) {
               // x still has its one child c to take (no room left, or the hint): all the general
@@ -837,8 +958,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               int slot = -1;
               uint32_t st8 = 0;
               if (act) {
-                slot = set_lookup_lane(keys, cap, rkey, &found);
-                if (found) st8 = state[slot];
+                slot = set_lookup_lane<2>(keys, cap, rkey, &found);
+                if (found) st8 = meta_state(state[slot]);
               }
               bool stop = act && (slot < 0 || (found && (st8 == ST_NODE || st8 == ST_ONSTACK)));
               // ... or repeats an earlier child of the run (a loop).  Every child of a run is a
@@ -854,10 +975,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               bool fresh = false;
               if (lane < f) {
                 if (!found) {
-                  slot = set_insert_lane(keys, cap, rkey, &fresh);
+                  slot = set_insert_lane<2>(keys, cap, rkey, &fresh);
                 }
                 if (slot >= 0) {
-                  state[slot] = (uint8_t)ST_ONSTACK;
+                  state[slot] = slot_meta(ST_ONSTACK, 0);
                   fk[depth + lane] = rkey; fc[depth + lane] = rcnt; fs[depth + lane] = (uint32_t)slot;
                 }
               }
@@ -899,7 +1020,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             const BranchFrame f = bf[bsp];
             for (uint32_t j = f.depth + lane; j < depth; j += 64) {
               const uint32_t s = fs[j];
-              if (state[s] == ST_ONSTACK) state[s] = (uint8_t)ST_POPPED;
+              if (meta_state(state[s]) == ST_ONSTACK) state[s] = slot_meta(ST_POPPED, 0);
             }
             depth = f.depth;
             if (reg > depth) reg = depth;
@@ -914,9 +1035,9 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           const uint64_t child = ((cur << 2) | c) & tab.kmask;
           const uint32_t ccnt = pick4(c4, c);
           bool found;
-          int slot = set_find(keys, cap, child, &found);
+          int slot = set_find<2>(keys, cap, child, &found);
           if (slot < 0) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
-          const uint32_t stt = found ? (uint32_t)state[slot] : 0u;
+          const uint32_t stt = found ? meta_state(state[slot]) : 0u;
           KM_DFS_STAMP(5);                                 // node-set probe of the child
           if (found && (stt == ST_NODE || stt == ST_ONSTACK)) {
             // rejoin (or loop): for p in stack: node_data[p] = jf.query(p)
@@ -926,9 +1047,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               if (n_nodes + add > node_cap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
               mem_sync();
               for (uint32_t j = reg + lane; j < depth; j += 64) {
-                a.node_kmer[nb + n_nodes + (j - reg)] = fk[j];
+                const uint64_t kx = fk[j];
+                a.node_kmer[nb + n_nodes + (j - reg)] = kx;
                 a.node_cnt[nb + n_nodes + (j - reg)] = fc[j];
-                state[fs[j]] = (uint8_t)ST_NODE;
+                state[fs[j]] = slot_meta(ST_NODE, n_nodes + (j - reg));
               }
               n_nodes += add;
               reg = depth;
@@ -945,21 +1067,21 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               bool wn;
               for (uint32_t j = lane; j < n_nodes; j += 64) {
                 const uint64_t kk = (j < n_ref) ? kmer_at(j) : a.node_kmer[nb + j];
-                const int s2 = set_insert_lane(keys, cap, kk, &wn);
-                if (s2 >= 0) state[s2] = (uint8_t)ST_NODE;
+                const int s2 = set_insert_lane<2>(keys, cap, kk, &wn);
+                if (s2 >= 0) state[s2] = slot_meta(ST_NODE, j);
               }
               __syncthreads();
               for (uint32_t j = lane; j < depth; j += 64) {
-                const int s2 = set_insert_lane(keys, cap, fk[j], &wn);
+                const int s2 = set_insert_lane<2>(keys, cap, fk[j], &wn);
                 if (s2 >= 0) {
-                  if (wn) state[s2] = (uint8_t)ST_ONSTACK;
+                  if (wn) state[s2] = slot_meta(ST_ONSTACK, 0);
                   fs[j] = (uint32_t)s2;
                 }
               }
               __syncthreads();
               set_count = n_nodes + (depth - reg);
               if (set_count + 1 > set_limit) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
-              slot = set_find(keys, cap, child, &found);
+              slot = set_find<2>(keys, cap, child, &found);
               if (slot < 0 || found) { st = T_INTERNAL; break; }
             }
             if (depth >= a.fcap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }   // fast tier: bounded frames
@@ -975,7 +1097,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             if (!found) ++set_count;
             if (lane == 0) {
               if (!found) keys[slot] = child;
-              state[slot] = (uint8_t)ST_ONSTACK;
+              state[slot] = slot_meta(ST_ONSTACK, 0);
               fk[depth] = child; fc[depth] = ccnt; fs[depth] = (uint32_t)slot;
             }
             parent_brk = brk;
@@ -991,7 +1113,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         mem_sync();
         for (uint32_t j = 1 + lane; j < depth; j += 64) {
           const uint32_t s = fs[j];
-          if (state[s] == ST_ONSTACK) state[s] = (uint8_t)ST_POPPED;
+          if (meta_state(state[s]) == ST_ONSTACK) state[s] = slot_meta(ST_POPPED, 0);
         }
         step_sync();
         // the next seed's __extend call (there is one unless this was the last
@@ -999,6 +1121,257 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         if (n_nodes > a.max_node && i + 1 < n_ref) st = T_NODE_LIMIT;
       }
     }
+  }
+
+  // ---- epilogue: the graph of nearly every flagged target, read off the node set --------------
+  // MutationFinder.graph_analysis + Graph (km/utils/MutationFinder.py:496-572, km/utils/Graph.py:63-240)
+  // on "reference chain + forward bubbles" is a closed form (graph_kernel.h 2c has the argument for one
+  // bubble; tests/test_bubble_theory.py checks the conditions below against the oracle for one and for
+  // several): edges are i -> j iff suffix(i) == prefix(j), so with
+  //  (R1) no two reference nodes sharing their (k-1)-mer prefix, nothing behind the last reference suffix,
+  //  (R2) a walk node sharing its prefix with at most one other node, and that one a reference node x >= 1
+  //       (both are children of a = x - 1): the walk node heads a bubble hanging off a,
+  //  (R3) the suffix of every walk node e being the prefix of exactly one node: e + 1, not itself a head,
+  //  (R4) or a reference node b, which ends the bubble (the next walk node, if any, heads the next): b > a
+  //       with (b - a) x 0.01 well below the bubble's cost, or b <= a (a tandem duplication: the
+  //       bubble leads back; both shortest-path trees stay on the reference chain then as well),
+  // the paths are the reference path and, per bubble, 0..a, the bubble, b..n_ref-1.  The node set of the
+  // walk answers "which node is this k-mer" (state NODE + index per slot), and "who has prefix P" is
+  // the four k-mers P+A, P+C, P+G, P+T: no prefix table, no adjacency, no Dijkstra.  Everything else
+  // (loops, dead ends, nested bubbles, a bubble cheaper than the reference route, more than
+  // EPI_MAX_BUBBLES of them) goes to k_graph through the `left` list, untouched.
+#ifndef KM_DFS_STAMPS
+  if (a.stamps) life2 = __builtin_amdgcn_s_memrealtime();
+#endif
+  bool answered = false;
+  if constexpr (!BIG) {
+    KM_DFS_STAMP(0);
+    const uint32_t m = n_nodes, n_walk = n_nodes - n_ref;
+    if (a.epi != nullptr && ref_pure && st == T_OK && n_ref >= 2 && n_walk <= 64u * EPI_CHUNKS && m < 0x3FFFu) {
+      constexpr uint32_t NONE = 0xFFFFFFFFu;
+      constexpr uint32_t REF_REGS = 8;                     // reference counts a lane keeps (targets of up to 512 k-mers)
+      // the nodes whose k-mer has the (k-1)-mer prefix P, the node `self` aside: how many, and one of
+      // them.  They all sit in the probe sequence that starts at P's home slot.
+      auto nodes_with_prefix = [&](uint64_t P, uint32_t self, uint32_t* one) -> uint32_t {
+        uint32_t cnt = 0, sl = set_home(P, cap);
+        for (uint32_t step = 0; step < cap; ++step) {
+          const uint64_t kv = keys[sl];
+          if (kv == EMPTY) break;
+          if ((kv >> 2) == P) {
+            const uint16_t mv = state[sl];
+            if (meta_state(mv) == ST_NODE && meta_index(mv) != self) { ++cnt; *one = meta_index(mv); }
+          }
+          if (++sl == cap) sl = 0;
+        }
+        return cnt;
+      };
+      const uint32_t* ncnt = a.node_cnt + nb;
+      // ---- everything that comes from memory is requested first: where to write, the k-mers and
+      // counts of the walk's nodes (lane l of chunk q owns node n_ref + 64 q + l), the reference's counts
+      const EpiArgs ea = *a.epi;
+      __syncthreads();                                     // node_kmer / node_cnt were stored by this wave
+      uint64_t w_x[EPI_CHUNKS];
+      uint32_t w_c[EPI_CHUNKS], rc[REF_REGS];
+#pragma unroll
+      for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
+        const uint32_t e = n_ref + 64u * q + lane;
+        w_x[q] = 0; w_c[q] = 0xFFFFFFFFu;
+        if (e < m) { w_x[q] = a.node_kmer[nb + e]; w_c[q] = ncnt[e]; }
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < REF_REGS; ++q) {
+        const uint32_t j = lane + 64u * q;
+        rc[q] = 0xFFFFFFFFu;
+        if (j < n_ref) rc[q] = ncnt[j];
+      }
+      uint32_t bad = 0;
+      const uint64_t last_suffix = kmer_at(n_ref - 1) & tab.pmask;    // (R1): no walk node behind it either
+      uint32_t w_a[EPI_CHUNKS], w_nx[EPI_CHUNKS];
+      unsigned long long Hm[EPI_CHUNKS], Em[EPI_CHUNKS];
+      // pass 1 — who shares a walk node's prefix: at most one node, a reference node x >= 1 (R2)
+#pragma unroll
+      for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
+        const uint32_t e = n_ref + 64u * q + lane;
+        bool head = false;
+        w_a[q] = 0; w_nx[q] = NONE;
+        if (64u * q < n_walk) {                            // wave-uniform
+          if (e < m) {
+            const uint64_t X = w_x[q];
+            if ((X >> 2) == last_suffix) bad = 1;
+            uint32_t other = NONE;
+            const uint32_t sh = nodes_with_prefix(X >> 2, e, &other);
+            if (sh > 1) bad = 1;
+            if (sh == 1) {
+              if (other >= n_ref || other < 1) bad = 1;    // two walk nodes share a prefix / off the source
+              head = true;
+              w_a[q] = other - 1;
+            }
+          }
+        }
+        Hm[q] = __ballot(head);
+      }
+      // pass 2 — who is behind a walk node's suffix (R3, R4).  Node e + 1 is, when its prefix is that
+      // suffix; the others behind it would share e + 1's prefix, i.e. make it a head (pass 1).  So a
+      // node followed by a non-head e + 1 with the right prefix is settled without a scan; the rest
+      // (the last node of every bubble) scan the cluster of their suffix: exactly one node, a
+      // reference node b.
+#pragma unroll
+      for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
+        const uint32_t e = n_ref + 64u * q + lane;
+        bool is_end = false;
+        if (64u * q < n_walk) {                            // wave-uniform
+          const uint64_t X = w_x[q];
+          // the next node's k-mer: lane + 1, or lane 0 of the next chunk
+          uint64_t Xn = (uint64_t)__shfl_down((unsigned long long)X, 1);
+          if (q + 1 < EPI_CHUNKS) { const uint64_t first_next = lane_u64(w_x[q + 1], 0); if (lane == 63) Xn = first_next; }
+          const unsigned long long Hn = (Hm[q] >> 1) | (q + 1 < EPI_CHUNKS ? (Hm[q + 1] << 63) : 0ull);
+          const bool next_head = (Hn >> lane) & 1ull;
+          const uint64_t S = X & tab.pmask;
+          const bool chained = e + 1 < m && (Xn >> 2) == S && !next_head;
+          if (e < m && !chained) {
+            uint32_t nx = NONE;
+            const uint32_t sc = nodes_with_prefix(S, NONE, &nx);
+            if (sc != 1 || nx >= n_ref) bad = 1;            // (a walk node behind it that is not e + 1, or e + 1 a head as well)
+            is_end = true;
+            w_nx[q] = nx;
+          }
+          if (e < m && chained) w_nx[q] = e + 1;
+        }
+        Em[q] = __ballot(is_end);
+      }
+      // a head follows every end and nothing else; the first walk node is a head, the last an end
+      uint32_t n_bub = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
+        const uint32_t e = n_ref + 64u * q + lane;
+        if (e < m) {
+          const unsigned long long Hn = (Hm[q] >> 1) | (q + 1 < EPI_CHUNKS ? (Hm[q + 1] << 63) : 0ull);
+          const bool next_head = (Hn >> lane) & 1ull;
+          const bool is_end = (Em[q] >> lane) & 1ull;
+          if (e + 1 < m ? (next_head != is_end) : !is_end) bad = 1;
+        }
+        n_bub += (uint32_t)__popcll(Em[q]);
+      }
+      if (n_walk && !(Hm[0] & 1ull)) bad = 1;
+      // per bubble (at its end node): a from its head, b, and — for a forward bubble — the margin that
+      // keeps both shortest-path trees on the reference edges
+      uint32_t my_a = 0, my_s = 0, my_e = 0, my_b = 0;     // lane r: bubble r (in node order)
+      if (!__any((int)bad) && n_bub <= EPI_MAX_BUBBLES) {
+        uint32_t rank_base = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
+          if (Em[q] == 0ull) continue;                     // wave-uniform
+          // head position at or before this lane's node, over the chunks up to q
+          uint32_t hpos = NONE;
+#pragma unroll
+          for (uint32_t q2 = 0; q2 <= q; ++q2) {
+            const unsigned long long hm = q2 == q ? (Hm[q2] & (~0ull >> (63 - lane))) : Hm[q2];
+            if (hm) hpos = 64u * q2 + 63u - (uint32_t)__clzll((long long)hm);
+          }
+          // a of that head: held by the lane that owns it
+          uint32_t a_here = 0;
+#pragma unroll
+          for (uint32_t q2 = 0; q2 <= q; ++q2) {
+            const uint32_t v = (uint32_t)__shfl((int)w_a[q2], (int)(hpos & 63u));
+            if (hpos != NONE && (hpos >> 6) == q2) a_here = v;
+          }
+          const bool is_end = (Em[q] >> lane) & 1ull;
+          const uint32_t e = n_ref + 64u * q + lane;
+          if (is_end) {
+            const uint32_t s_node = n_ref + hpos, b_node = w_nx[q];
+            if (hpos == NONE || b_node > n_ref - 1 ||
+                (a_here < b_node && (uint64_t)(b_node - a_here) + 10 > 100ull * (e - s_node + 2))) bad = 1;
+          }
+          // hand bubble r to lane r
+          for (unsigned long long em = Em[q]; em; em &= em - 1) {
+            const uint32_t l = (uint32_t)__ffsll((long long)em) - 1;
+            const uint32_t r = rank_base + (uint32_t)__popcll(Em[q] & ((1ull << l) - 1ull));
+            const uint32_t va = lane_u32(a_here, l), vs = lane_u32(hpos, l), vb = lane_u32(w_nx[q], l);
+            if (lane == r) { my_a = va; my_s = n_ref + vs; my_e = n_ref + 64u * q + l; my_b = vb; }
+          }
+          rank_base += (uint32_t)__popcll(Em[q]);
+        }
+      }
+      if (!__any((int)bad) && n_bub <= EPI_MAX_BUBBLES) {
+        // ---- emission (graph_kernel.h: emit_bubble, for every bubble).  The pool space is asked for
+        // now; the answer is needed only after the coverages are known
+        const uint32_t pg = t % POOL_GROUPS;
+        const uint64_t pg_paths = ea.path_pool / POOL_GROUPS, pg_runs = ea.run_pool / POOL_GROUPS;
+        unsigned long long pb = 0, rb = 0;
+        if (lane == 0) {
+          unsigned long long* ctr = ea.counters + (uint64_t)pg * POOL_CTR_STRIDE;
+          pb = atomicAdd(&ctr[0], 1ull + n_bub);
+          rb = atomicAdd(&ctr[1], 1ull + 3ull * n_bub);
+        }
+        uint32_t ref_min = 0xFFFFFFFFu, ref_max = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < REF_REGS; ++q) {
+          const uint32_t j = lane + 64u * q;
+          if (j < n_ref) { ref_min = rc[q] < ref_min ? rc[q] : ref_min; ref_max = rc[q] > ref_max ? rc[q] : ref_max; }
+        }
+        for (uint32_t j = lane + 64u * REF_REGS; j < n_ref; j += 64) {       // longer targets
+          const uint32_t cv = ncnt[j];
+          ref_min = cv < ref_min ? cv : ref_min;
+          ref_max = cv > ref_max ? cv : ref_max;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t x0 = __shfl_xor(ref_min, o); ref_min = x0 < ref_min ? x0 : ref_min;
+          const uint32_t x1 = __shfl_xor(ref_max, o); ref_max = x1 > ref_max ? x1 : ref_max;
+        }
+        uint32_t my_mc = 0xFFFFFFFFu;
+        for (uint32_t r = 0; r < n_bub; ++r) {             // wave-uniform
+          const uint32_t ba = lane_u32(my_a, r), bs = lane_u32(my_s, r), be = lane_u32(my_e, r), bb = lane_u32(my_b, r);
+          uint32_t mc = 0xFFFFFFFFu;                       // min over 0..a, s..e, b..n_ref-1
+#pragma unroll
+          for (uint32_t q = 0; q < REF_REGS; ++q) {
+            const uint32_t j = lane + 64u * q;
+            if (j < n_ref && (j <= ba || j >= bb)) mc = rc[q] < mc ? rc[q] : mc;
+          }
+          for (uint32_t j = lane + 64u * REF_REGS; j < n_ref; j += 64)
+            if (j <= ba || j >= bb) { const uint32_t cv = ncnt[j]; mc = cv < mc ? cv : mc; }
+#pragma unroll
+          for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
+            const uint32_t e = n_ref + 64u * q + lane;
+            if (e >= bs && e <= be) mc = w_c[q] < mc ? w_c[q] : mc;
+          }
+          for (int o = 32; o > 0; o >>= 1) { const uint32_t x0 = __shfl_xor(mc, o); mc = x0 < mc ? x0 : mc; }
+          if (lane == r) my_mc = mc;
+        }
+        pb = lane_u64(pb, 0);
+        rb = lane_u64(rb, 0);
+        if (pb + 1 + n_bub > pg_paths || rb + 1 + 3ull * n_bub > pg_runs) {
+          // pools exhausted: the host enlarges them and reruns the graph stage over every flagged target
+          if (lane == 0) {
+            atomicExch(ea.counters + (uint64_t)POOL_GROUPS * POOL_CTR_STRIDE, 1ull);
+            ea.t_npaths[t] = 0; ea.t_pathbase[t] = 0; ea.t_nruns[t] = 0; ea.t_refmax[t] = NOT_BARE; ea.g_status[t] = T_OK;
+          }
+        } else {
+          pb += (uint64_t)pg * pg_paths;
+          rb += (uint64_t)pg * pg_runs;
+          if (lane == 0) {
+            ea.r_start[rb] = 0; ea.r_len[rb] = n_ref;
+            ea.p_target[pb] = t; ea.p_runbase[pb] = rb; ea.p_nruns[pb] = 1; ea.p_len[pb] = n_ref; ea.p_mincov[pb] = ref_min;
+            ea.t_npaths[t] = 1 + n_bub; ea.t_pathbase[t] = (uint32_t)pb; ea.t_nruns[t] = 1 + 3 * n_bub;
+            ea.t_refmax[t] = n_bub ? NOT_BARE : ref_max;
+            ea.g_status[t] = T_OK;
+          }
+          if (lane < n_bub) {
+            const uint64_t r0 = rb + 1 + 3ull * lane, p0 = pb + 1 + lane;
+            ea.r_start[r0] = 0; ea.r_len[r0] = my_a + 1;
+            ea.r_start[r0 + 1] = my_s; ea.r_len[r0 + 1] = my_e - my_s + 1;
+            ea.r_start[r0 + 2] = my_b; ea.r_len[r0 + 2] = n_ref - my_b;
+            ea.p_target[p0] = t; ea.p_runbase[p0] = r0; ea.p_nruns[p0] = 3;
+            ea.p_len[p0] = (my_a + 1) + (my_e - my_s + 1) + (n_ref - my_b); ea.p_mincov[p0] = my_mc;
+          }
+        }
+        answered = true;
+      }
+    }
+    if (a.epi != nullptr && !answered && lane == 0) {
+      a.epi->t_refmax[t] = NOT_BARE;
+      a.epi->left[atomicAdd(a.epi->n_left, 1u)] = t;
+    }
+    KM_DFS_STAMP(14);                                      // epilogue
   }
 
 #ifdef KM_DFS_STAMPS
@@ -1009,8 +1382,16 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     for (int q = 0; q < 16; ++q) o[q] = dfs_acc[q];
     o[16] = dfs_steps; o[17] = (uint32_t)tend - dfs_t0; o[18] = t; o[19] = probes_u;
     o[20] = dfs_loads; o[21] = dfs_nonres; o[22] = dfs_maxS; o[23] = dfs_general; o[24] = dfs_runs;
-    o[25] = dfs_t_setup - dfs_t0; o[26] = n_nodes - n_ref;
+    o[25] = dfs_t_setup - dfs_t0; o[26] = n_nodes - n_ref; o[27] = dfs_nstamps;
+    o[28] = __builtin_amdgcn_s_memrealtime() - dfs_real0;   // 100 MHz
     o[31] = 0x6466735f7374616dull;                         // record marker
+  }
+#endif
+#ifndef KM_DFS_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + 32ull * blockIdx.x;
+    o[0] = life0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = t; o[3] = n_nodes - n_ref; o[4] = life1; o[5] = life2; o[6] = 0; o[7] = lifeB; o[8] = lifeC;
+    o[31] = 0x6c6966655f646673ull;
   }
 #endif
   if (lane == 0) {

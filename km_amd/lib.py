@@ -25,7 +25,7 @@ SYMBOLS = [
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
-    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_pump", "km_batch_debug_stamps",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_pump", "km_batch_debug_stamps", "km_batch_debug_counts",
     "km_report_rows", "km_report_free", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
@@ -139,6 +139,7 @@ def load():
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
         "km_batch_pump": [C.POINTER(vp), C.POINTER(vp), i32, i32, i32],
         "km_batch_debug_stamps": [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)],
+        "km_batch_debug_counts": [vp, C.POINTER(C.c_uint32)],
         "km_report_rows": [C.POINTER(ReportIn), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
                            C.POINTER(C.POINTER(C.c_int32))],
         "km_device_count": [C.POINTER(i32)],
@@ -356,6 +357,12 @@ class Batch:
         ms = (C.c_float * 8)()
         check(self._lib.km_batch_timings(self._b, ms))
         return tuple(float(x) for x in ms)
+
+    def debug_counts(self):
+        """(flagged targets, unflagged ones handed to k_graph, flagged ones the epilogue of k_dfs left to k_graph)."""
+        out = (C.c_uint32 * 4)()
+        check(self._lib.km_batch_debug_counts(self._b, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def debug_stamps(self):
         """k_seed time stamps (KM_SEED_STAMPS diagnostics): uint64 array [n_waves, 16]."""

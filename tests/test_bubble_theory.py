@@ -97,10 +97,11 @@ def test_closed_form_equals_the_reference_algorithm(k):
     assert n_shape >= 10 and n_other >= 10, (n_shape, n_other)       # both sides of the conditions were met
 
 
-def bubbles_shape(kmers, n_ref):
-    """Generalisation (not in the kernel yet): the reference chain plus ANY number of
-    forward bubbles, each a run of consecutive walk nodes s..e hanging off reference node a and
-    leading back to reference node b > a.  Returns [(a, s, e, b)] or None."""
+def bubbles_shape(kmers, n_ref, allow_back=False):
+    """The shape the epilogue of k_dfs answers (walk_kernel.h): the reference chain plus ANY number of
+    bubbles, each a run of consecutive walk nodes s..e hanging off reference node a and leading back to
+    reference node b — forward (b > a, with the cost margin) or, with allow_back, backward (b <= a: a
+    tandem duplication).  Returns [(a, s, e, b)] or None."""
     m = len(kmers)
     if not (m > n_ref >= 2):
         return None
@@ -138,7 +139,12 @@ def bubbles_shape(kmers, n_ref):
             if nxt != e + 1 or nxt in head_of:
                 return None
             e = nxt
-        if not (a < b <= n_ref - 1) or (b - a) + 10 > 100 * (e - s + 2):
+        if b > n_ref - 1:
+            return None
+        if a < b:
+            if (b - a) + 10 > 100 * (e - s + 2):
+                return None
+        elif not allow_back:
             return None
         bubbles.append((a, s, e, b))
         e += 1
@@ -176,3 +182,40 @@ def test_closed_form_for_several_bubbles(k):
             got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
             assert got == want, (k, trial, name, shape, n_ref, len(kmers))
     assert n_multi >= 10, n_multi
+
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+def test_closed_form_with_backward_bubbles(k):
+    """Tandem duplications: the bubble leads BACK to a reference node b <= a.  The path through it is
+    still 0..a, the bubble, b..n_ref-1 (b..a twice), next to the reference path and one path per other
+    bubble — what the epilogue of k_dfs writes for them, checked against the oracle."""
+    rng = np.random.default_rng(4242 + k)
+    n_back = n_mixed = 0
+    for trial in range(24):
+        spec = dict(n_targets=12, length=int(rng.integers(5 * k + 8, 400)), k=k, n_keys=3000,
+                    seed=int(rng.integers(1, 1 << 30)), variant_frac=1.0,
+                    variants_per_target=(1, int(rng.integers(1, 4))), kinds=("snv", "ins", "del", "dup"),
+                    vaf=(0.2, 0.8), noise_frac=float(rng.choice([0.0, 0.03])), cov=(60, 400))
+        case = synth.make_case(**spec)
+        db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                       records={"k": k, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+        for row, name in zip(case["targets"], case["names"]):
+            seq = km.decode(row)
+            try:
+                mers = ko.ref_kmers(seq, name, k)
+                nodes = ko.walk(mers, db)
+            except (ValueError, ko.NodeLimit):
+                continue
+            kmers = list(nodes.keys())
+            n_ref = len(mers)
+            shape = bubbles_shape(kmers, n_ref, allow_back=True)
+            if shape is None:
+                continue
+            back = sum(1 for a, s, e, b in shape if b <= a)
+            n_back += back > 0 and back == len(shape)
+            n_mixed += 0 < back < len(shape)
+            want = sorted([tuple(range(n_ref))] +
+                          [tuple(range(a + 1)) + tuple(range(s, e + 1)) + tuple(range(b, n_ref)) for a, s, e, b in shape])
+            got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
+            assert got == want, (k, trial, name, shape, n_ref, len(kmers))
+    assert n_back >= 10 and n_mixed >= 10, (n_back, n_mixed)

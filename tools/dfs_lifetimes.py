@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostics: when do the waves of k_dfs start and end?  (normal build, KM_SEED_STAMPS set: every working
+wave records s_memrealtime at entry and exit.)  usage: dfs_lifetimes.py [n_keys]"""
+import os
+import sys
+
+os.environ["KM_SEED_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from km_amd import lib as kmlib, synth  # noqa: E402
+
+T, L, K = 10000, 500, 31
+nk = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+case = synth.make_case(n_targets=T, length=L, k=K, n_keys=nk, seed=synth.HEADLINE_SEED, exact_pad=False)
+db = kmlib.Database.from_records(case["keys"], case["counts"], K).upload(0)
+b = kmlib.Batch(db, max_targets=T, max_total_bases=T * L)
+blob = np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy().reshape(-1)
+b.set_targets_packed(blob, np.arange(T + 1, dtype=np.uint64) * np.uint64(L))
+st = kmlib.stream_create(0)
+flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_TIMED | kmlib.KM_RUN_SERIAL
+tm = []
+for _ in range(6):
+    b.run(flags, st)
+    b.sync()
+    tm.append(b.timings()[5])
+rec = b.debug_stamps().reshape(-1, 32)
+rec = rec[rec[:, 31] == 0x6C6966655F646673]
+t0, t1 = rec[:, 0].astype(np.float64) / 100.0, rec[:, 1].astype(np.float64) / 100.0      # us
+base = t0.min()
+life = t1 - t0
+print("k_dfs %.1f us by HIP events (k_seed runs its stamped variant in this mode); %d working waves" % (np.mean(tm[2:]) * 1e3, len(rec)))
+print("wave start after the first one: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.percentile(t0 - base, [50, 90, 99, 100])))
+print("wave lifetime: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.percentile(life, [50, 90, 99, 100])))
+print("last wave ends %.1f us after the first one starts" % (t1.max() - base))
+ts, tw = rec[:, 4].astype(np.float64) / 100.0, rec[:, 5].astype(np.float64) / 100.0
+print("phases, all waves: setup p50 %.1f p99 %.1f, walk p50 %.1f p99 %.1f, epilogue p50 %.1f p99 %.1f us" %
+      (np.percentile(ts - t0, 50), np.percentile(ts - t0, 99), np.percentile(tw - ts, 50), np.percentile(tw - ts, 99),
+       np.percentile(t1 - tw, 50), np.percentile(t1 - tw, 99)))
+tA, tB, tC = (rec[:, q].astype(np.float64) / 100.0 for q in (6, 7, 8))
+print("setup, p50: header + packed words %.1f, clears %.1f, node set (+ the purity of the reference) %.1f us" %
+      (np.median(tB - t0), np.median(tC - tB), np.median(ts - tC)))
+order = np.argsort(-(t1 - base))[:8]
+for i in order:
+    print("  target %5d: start %.1f, setup %.1f, walk %.1f, epilogue %.1f, end %.1f us, %d new nodes" %
+          (rec[i, 2], t0[i] - base, ts[i] - t0[i], tw[i] - ts[i], t1[i] - tw[i], t1[i] - base, rec[i, 3]))
+b.close()
+db.close()

@@ -32,25 +32,28 @@ b = kmlib.Batch(db, max_targets=T, max_total_bases=T * L)
 blob = np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy().reshape(-1)
 b.set_targets_packed(blob, np.arange(T + 1, dtype=np.uint64) * np.uint64(L))
 st = kmlib.stream_create(0)
-flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
-for _ in range(3):
+flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_TIMED | kmlib.KM_RUN_SERIAL
+tm = []
+for _ in range(8):
     b.run(flags, st)
     b.sync()
+    tm.append(b.timings()[5])
+print("k_dfs of this (stamped) build: %.1f us by HIP events" % (np.mean(tm[3:]) * 1e3))
 rec = b.debug_stamps().reshape(-1, 32)
 rec = rec[rec[:, 31] == 0x6466735F7374616D]
 names = ["other", "late request", "wait+resolve", "next request", "unwind", "set probe", "rejoin", "push/booking",
          "thresholds", "next key", "chain: find", "chain: bucket change", "chain: non-resident lookup",
-         "chain: end expansion", "-", "-"]
+         "chain: end expansion", "epilogue", "-"]
 tot = rec[:, 17].astype(np.float64)
 setup = rec[:, 25].astype(np.float64)
 order = np.argsort(-tot)
-print("%d k_dfs waves; shader-clock ticks; longest eight:" % len(rec))
+print("%d k_dfs waves; shader-clock ticks; s_memtime ticks per microsecond of s_memrealtime (100 MHz): median %.0f; longest eight:" % (len(rec), np.median(rec[:, 17] / (rec[:, 28] / 100.0))))
 for i in order[:8]:
     r = rec[i]
     sec = r[:16].astype(np.float64)
     print("  target %5d: %7d ticks (setup %5d, unaccounted %5d), %3d steps of which %2d general, %d runs, %2d bucket "
-          "loads (largest %4d slots), %3d non-resident lookups, %3d new nodes:\n      " %
-          (r[18], r[17], r[25], r[17] - r[25] - sec.sum(), r[16], r[23], r[24], r[20], r[22], r[21], r[26]) +
+          "loads (largest %4d slots), %3d non-resident lookups, %3d new nodes, %d stamps:\n      " %
+          (r[18], r[17], r[25], r[17] - r[25] - sec.sum(), r[16], r[23], r[24], r[20], r[22], r[21], r[26], r[27]) +
           ", ".join("%s %d" % (nm, v) for nm, v in zip(names, sec) if v))
 print("bucket loads %d, chain lookups in a bucket too large for the lanes %d, largest bucket %d slots; "
       "loads per wave p50 %d max %d" % (rec[:, 20].sum(), rec[:, 21].sum(), rec[:, 22].max(), np.median(rec[:, 20]), rec[:, 20].max()))
