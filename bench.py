@@ -238,6 +238,112 @@ def oracle_check(case, views, set_ids, T, n_check):
             "oracle_keys": int(len(case["keys"])), "oracle_build_s": t_build}
 
 
+def hard_workload(args, case, dev_index, stream, T, n_fl):
+    """BASELINE config 4's shape made hard (example/run_leucegene.sh:13-35 is what real catalogs
+    look like): 85 % of the targets carry 1-3 variants of every kind (15 % of them homozygous), 3 % of the
+    k-mers an above-threshold dead-end branch, 3 % sub-threshold noise, and 4 % of the variant targets 3-5
+    tandem duplications (walks that outgrow the LDS tier).  Its table: the hard targets' own k-mers plus the
+    headline case's random pads, 100 M keys.  Returns the `config4_hard` object; every number is this
+    workload's own, including an oracle check against the plain-C oracle over the same table."""
+    from km_amd import lib as kmlib, synth
+    from oracle import c_oracle
+    t0 = time.perf_counter()
+    n_sets = 2
+    hc = synth.make_case(n_targets=n_sets * T, length=args.length, k=K, n_keys=1, seed=synth.HEADLINE_SEED + 7,
+                         variant_frac=0.85, variants_per_target=(1, 3), hom_frac=0.15, branch_noise_frac=0.03,
+                         noise_frac=0.03, heavy_frac=0.04, exact_pad=False)
+    real_k, real_c = hc["keys"][:hc["n_real"]], hc["counts"][:hc["n_real"]]
+    pads_k, pads_c = case["keys"][case["n_real"]:], case["counts"][case["n_real"]:]
+    n_pad = max(0, min(len(pads_k), args.keys - len(real_k)))
+    pk, pc = pads_k[:n_pad], pads_c[:n_pad]
+    pos = np.searchsorted(real_k, pk)
+    pos[pos >= len(real_k)] = len(real_k) - 1
+    ok = real_k[pos] != pk
+    keys = np.concatenate([real_k, pk[ok]])
+    cnts = np.concatenate([real_c, pc[ok]])
+    t_gen = time.perf_counter() - t0
+    db = kmlib.Database.from_records(keys, cnts, K).upload(dev_index)
+    offsets = (np.arange(T + 1, dtype=np.uint64) * np.uint64(args.length))
+    blob = np.frombuffer(b"ACGT", dtype=np.uint8)[hc["targets"]].copy()
+    streams = [kmlib.stream_create(dev_index) for _ in range(n_fl)]
+    batches = []
+    for q in range(n_fl):
+        bq = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
+                         max_targets=T, max_total_bases=T * args.length)
+        sid = q % n_sets
+        bq.set_targets_packed(blob[sid * T:(sid + 1) * T].reshape(-1), offsets)
+        batches.append(bq)
+    stages = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    deliver = stages | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN
+    kmlib.pump(batches, streams, max(n_fl, args.warmup), deliver)
+    dts = []
+    for _ in range(max(1, args.repeats)):
+        t1 = time.perf_counter()
+        kmlib.pump(batches, streams, args.steps, deliver)
+        dts.append(time.perf_counter() - t1)
+    dt = float(np.median(dts))
+    sizes = [bq.wait_result() for bq in batches]
+    views = [bq.result() for bq in batches]
+    tm = []
+    for i in range(args.steps):
+        bq, sq = batches[i % n_fl], streams[i % n_fl]
+        bq.run(deliver | kmlib.KM_RUN_TIMED | kmlib.KM_RUN_SERIAL, sq)
+        bq.wait_result()
+        tm.append(bq.timings())
+    tm = np.mean(np.array(tm), axis=0)
+    counts = [bq.debug_counts() for bq in batches[:n_sets]]
+    # oracle check: targets spread over both sets, plus every large-tier target among the first 2 000 of set 0
+    co = c_oracle.COracle(keys, cnts, K)
+    check = {"ok": True, "checked": 0, "with_variant_paths": 0, "max_paths": 0}
+    for sid in range(n_sets):
+        v = views[sid]
+        noff, xoff, poff = (v[x].astype(np.int64) for x in ("node_off", "extra_off", "path_off"))
+        for t in range(0, T, max(1, T // max(1, args.check // n_sets))):
+            want = co.analyse(hc["targets"][sid * T + t])
+            nr = int(v["n_ref"][t])
+            ok = int(v["status"][t]) == want["status"] == 0
+            if noff[t + 1] == noff[t]:
+                ok = ok and len(want["counts"]) == nr and int(v["ref_max_cov"][t]) == int(want["counts"].max())
+                ok = ok and want["paths"] == [list(range(nr))]
+            else:
+                ok = ok and (v["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all()
+            ok = ok and (v["extra_kmer"][xoff[t]:xoff[t + 1]] == want["kmers"][nr:]).all()
+            ok = ok and int(v["probes"][t]) == want["probes"]
+            got = [kmlib.expand_path(v, p).tolist() for p in range(poff[t], poff[t + 1])]
+            ok = ok and got == want["paths"] and v["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"]
+            if not ok:
+                check = {"ok": False, "first_mismatch": {"set": sid, "target": t}, "checked": check["checked"]}
+                break
+            check["checked"] += 1
+            check["with_variant_paths"] += len(got) > 1
+            check["max_paths"] = max(check["max_paths"], len(got))
+        if not check["ok"]:
+            break
+    probes = float(np.mean([int(s.logical_probes) for s in sizes]))
+    out = {"workload": "synthetic_hard_%dx%dnt_targets_%dM_kmer_table_k31: 85%% of the targets with 1-3 variants (snv/ins/del/dup, "
+                       "15%% homozygous), 3%% above-threshold dead-end branches, 3%% sub-threshold noise, 4%% of the variant targets "
+                       "with 3-5 tandem duplications" % (T, args.length, round(len(keys) / 1e6)),
+           "value": T / (dt / args.steps), "unit": "targets/s", "ms_per_step": dt / args.steps * 1e3,
+           "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3,
+           "distinct_target_sets": n_sets, "batches_in_flight": n_fl, "delivery": "lean",
+           "logical_probes_per_step": probes, "gprobes_per_s": probes / (dt / args.steps) / 1e9,
+           "targets_flagged": [c[0] for c in counts], "targets_left_to_k_graph": [c[1] + c[2] for c in counts],
+           "targets_in_large_tier": [int(s.n_big_tier) for s in sizes[:n_sets]],
+           "paths_per_step": float(np.mean([int(s.n_paths) for s in sizes])),
+           "kernel_ms": {"walk": float(tm[0]), "k_pack": float(tm[4]), "k_seed": float(tm[3]), "k_dfs": float(tm[5]),
+                         "graph": float(tm[1]), "deliver_kernels": float(tm[6]), "d2h_copy": float(tm[7]),
+                         "note": "one batch at a time, every kernel alone (KM_RUN_SERIAL); the large tier runs on the host's "
+                                 "request after these kernels and is part of ms_per_step, not of kernel_ms"},
+           "walk_stage_frac_of_hbm_peak": probes * BYTES_PER_PROBE / (float(tm[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "oracle_check": check, "setup_s": {"generate": t_gen}}
+    for bq in batches:
+        bq.close()
+    for st_ in streams:
+        kmlib.stream_destroy(st_)
+    db.close()
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -278,6 +384,10 @@ def main():
                     help="KM_RUN_SERIAL on every run: each kernel alone on the GPU, one stream (the command "
                          "behind profiles/*kernel_stats.csv: rocprofv3 then times the kernels as the roofline "
                          "section does)")
+    ap.add_argument("--no-hard", dest="hard", action="store_false",
+                    help="skip the second workload (config4_hard: several variants per target, branch noise, large-tier walks)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how often the timed region (exactly --steps steps) is repeated; value = the median")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
@@ -327,6 +437,15 @@ def main():
         else:
             dist.init_process_group(args.backend)
         dist.barrier()
+    # which ranks and devices take part (so that a driver can confirm N ranks on N devices)
+    ranks_seen = {"world_size": world, "backend": args.backend if world > 1 else None,
+                  "devices": [int(torch.cuda.current_device())]}
+    if world > 1:
+        mine = torch.tensor([rank, int(torch.cuda.current_device())], dtype=torch.int64, device=bdev)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ranks_seen["devices"] = [int(x[1].item()) for x in sorted(seen, key=lambda v: int(v[0].item()))]
+        ranks_seen["world_size"] = int(dist.get_world_size())
     from km_amd import dist as kd
     from km_amd import lib as kmlib
     from km_amd import synth
@@ -449,7 +568,8 @@ def main():
         check_full = oracle_check(case, views_full, set_ids, T, max(n_fl, args.check // 4))
     del views_full
     pipeline(n_fl, deliver, True)
-    dt = timed(deliver, True)
+    dts = [timed(deliver, True) for _ in range(max(1, args.repeats))]      # each: exactly K steps
+    dt = float(np.median(dts))
     views, out_bytes = delivered_bytes()
     # the same timed region driven from the interpreter (wait_result + run per step), for the record
     dt_py = None
@@ -464,7 +584,7 @@ def main():
         log("oracle check:", check)
     del views
     # kernel-only rate (results stay in HBM): what round 1 reported as `value`
-    dt_kernel = timed(stages, False)
+    dt_kernel = float(np.median([timed(stages, False) for _ in range(max(1, args.repeats))]))
 
     # ---- one step at a time (no pipelining), with and without delivery -------------------------
     batch = batches[0]
@@ -476,12 +596,15 @@ def main():
         batch.wait_result()
     serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
     # ---- per-kernel durations (HIP events on the launch stream), averaged over K launches
+    # one batch at a time, rotating over the n_fl distinct target sets (each has its own table lines:
+    # a set replayed back to back would find part of them in the 256 MiB Infinity Cache)
     def event_times(flags):
         tm = []
-        for _ in range(args.steps):
-            batch.run((flags & ~kmlib.KM_RUN_HIPGRAPH) | kmlib.KM_RUN_TIMED, st0)
-            batch.wait_result()
-            tm.append(batch.timings())
+        for i in range(args.steps):
+            bq, sq = batches[i % n_fl], tstreams[i % n_fl]
+            bq.run((flags & ~kmlib.KM_RUN_HIPGRAPH) | kmlib.KM_RUN_TIMED, sq)
+            bq.wait_result()
+            tm.append(bq.timings())
         return [float(x) for x in np.mean(np.array(tm), axis=0)]
 
     # every kernel alone on the GPU (KM_RUN_SERIAL: the pass over the unflagged targets follows k_dfs
@@ -512,6 +635,13 @@ def main():
                   "value": Ts * world / (dts / args.steps), "unit": "targets/s", "scaling": "strong"}
         for q in range(n_fl):
             batches[q].set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
+
+    # ---- a hard workload beside the headline one ------------------------------------------------------
+    hard = None
+    if rank == 0 and world == 1 and args.hard and not args.only_step:
+        hard = hard_workload(args, case, local_rank, stream, T, n_fl)
+        log("config4_hard:", {k_: hard[k_] for k_ in ("value", "ms_per_step", "targets_flagged", "targets_left_to_k_graph",
+                                                       "targets_in_large_tier", "oracle_check")})
 
     # ---- end to end through the drop-in host path: strings -> GPU -> TSV rows -----------------
     e2e = None
@@ -649,13 +779,21 @@ def main():
         alg_seed = seed_probes * BYTES_PER_PROBE
         alg_dfs = (probes_per_step - seed_probes) * BYTES_PER_PROBE
         walk_achieved = gb(alg_walk, walk_avg)
-        traffic = None
+        # HBM traffic of the walk stage: PMC counters need their own rocprofv3 passes (the guide: separate
+        # --pmc runs), so this number is NOT measured by this process — it is read from the committed
+        # summary of tools/collect_evidence.sh, and the line says so
+        traffic = traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("walk_stage_hbm_bytes_per_step")
+                pj = json.load(open(pmc))
+                traffic = pj.get("walk_stage_hbm_bytes_per_step")
+                traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
+                                  "collected_by": pj.get("collected_by", "tools/collect_evidence.sh (rocprofv3 --pmc passes over "
+                                                         "bench.py --only-step --inflight 1 --serial)"),
+                                  "commit": pj.get("commit"), "round": pj.get("round")}
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         out = {
             "metric": "find_mutation_targets_per_sec",
             "value": value,
@@ -664,6 +802,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "timed_region": {"repeats": len(dts), "steps_each": args.steps, "value_is": "median",
+                             "ms_per_step_median": ms_per_step, "ms_per_step_min": min(dts) / args.steps * 1e3,
+                             "ms_per_step_max": max(dts) / args.steps * 1e3},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -678,6 +819,9 @@ def main():
                        "params": "-c 5 -p 0.05 -s 500 -b 10 -n 10000",
                        "stages": both_names + " + result delivery (device compaction, D2H to pinned host memory)",
                        "distinct_target_sets": n_fl,
+                       "value_is": ("BASELINE config 4 on one GPU (10 000 targets x 500 nt, 100 M-key table)" if world == 1 else
+                                    "weak scaling of config 4's shape: %d targets per GPU per step; config 4 PROPER (10 000 targets "
+                                    "sharded over the %d GPUs) is the side key config4_strong" % (T, world)),
                        "parallelism": "target-sharded x%d, table replicated (records broadcast once over RCCL)" % world},
             "value_includes": "k_pack, k_seed, k_dfs, k_graph_pure, k_graph, k_out_scan, k_out_pack and the D2H of the "
                               "lean delivery into pinned host memory",
@@ -712,7 +856,9 @@ def main():
             "result_fetch_ms": outk_avg + d2h_avg,
             "result_fetch_copying_api_ms": fetch_s * 1e3,
             "oracle_check": check,
+            "ranks_seen": ranks_seen,
             "config4_strong": strong,
+            "config4_hard": hard,
             "config5_samples": cfg5,
             "end_to_end_host_path": e2e,
             "single_target_latency": single,
@@ -724,6 +870,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "walk stage (k_pack + k_seed + k_dfs)",
                          "achieved": walk_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": walk_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_walk,
                          "logical_probes_per_launch": probes_per_step,
                          "avg_launch_ms": walk_avg,
@@ -740,6 +887,9 @@ def main():
         print(json.dumps(out), flush=True)
         if check is not None and not check["ok"]:
             log("ORACLE CHECK FAILED:", check)
+            rc = 3
+        if hard is not None and not hard["oracle_check"]["ok"]:
+            log("ORACLE CHECK FAILED (config4_hard):", hard["oracle_check"])
             rc = 3
     # release the library's device / pinned memory while the HIP runtime is still up
     for bq in batches:

@@ -217,7 +217,10 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
 int km_batch_run(km_batch_t* b, int stages, void* stream);
 int km_batch_sync(km_batch_t* b);
 /* Sizes of the arrays km_batch_fetch fills (a full delivery; km_batch_result reports the sizes
- * of the delivery it returns, which may be lean). */
+ * of the delivery it returns, which may be lean).  NOTE: after a LEAN km_batch_result both
+ * km_batch_sizes and km_batch_fetch deliver again, in full, into the same pinned buffer (which may
+ * be reallocated): views handed out by that km_batch_result are invalid afterwards — copy what is
+ * still needed first, or ask for the full form only. */
 int km_batch_sizes(km_batch_t* b, km_batch_sizes_t* sizes);
 int km_batch_fetch(km_batch_t* b, const km_batch_out_t* out);
 /* Zero-copy variant: waits for the delivery of the last run (finishing, if some target needed
@@ -253,13 +256,22 @@ typedef struct {
   const km_batch_out_t* res;     /* arrays of km_batch_fetch or km_batch_result: everything but
                                     aux / probes / path_len; node_kmer may be NULL when
                                     extra_off / extra_kmer are given                          */
+  const km_batch_sizes_t* sizes; /* the lengths of those arrays (km_batch_sizes / km_batch_result), or NULL.
+                                    With them every offset array is checked against its array's length
+                                    before anything is read (KM_E_ARG on a mismatch); without them the
+                                    offsets are taken at their word.  Either way every node index of
+                                    a path is checked against its target's node count: a target
+                                    whose view is inconsistent gets err 5 and no rows, it is never
+                                    read or written out of bounds.                                */
 } km_report_in_t;
 /* text: the TSV rows of every KM_T_OK target, each row terminated by '\n' (the text as a whole is
  * what `km find_mutation` prints between its header and its trailer);
  * row_off[t] .. row_off[t+1] is the block of target t (empty for other statuses);
  * err[t] != 0 where the reference would have raised while naming a variant
  * (1 IndexError, 2 "mutation identification could be incorrect", 3 AssertionError,
- * 4 ValueError; no rows then), or 100 = rows delivered, but a printed rVAF / expression sits
+ * 4 ValueError, 5 = the view of this target is inconsistent — offsets not monotone, a path node
+ * beyond the target's nodes, counts missing for a target that has variant paths; no rows then), or
+ * 100 = rows delivered, but a printed rVAF / expression sits
  * within 1e-6 of a %.3f / %.1f rounding tie, where the last bits of the least-squares solver
  * decide the digit: a caller that needs the reference's exact text recomputes that target with
  * numpy (km_amd.lib.report_rows does).  Release the three arrays with km_report_free. */

@@ -9,6 +9,7 @@ rank per GPU: targets sharded for ``find_mutation``, samples sharded for ``sampl
 """
 
 import argparse
+import io
 import os
 import sys
 import time
@@ -57,6 +58,7 @@ def read_target(path):
 
 
 CHUNK = 8192          # targets per GPU batch; rows are flushed after every batch
+STREAM_ABOVE = 2_000_000   # catalogs larger than this are printed batch by batch (see main_find_mut)
 
 
 def _verbose_lines(name_seq, raw, t, k, err):
@@ -113,6 +115,8 @@ def main_find_mut(args, out=None, err=None):
     if world > 1:
         # one process per GPU (torchrun, or KM_DEVICES=0,1,.. which starts the ranks): targets are
         # sharded, the database records cross the links once, rank 0 prints in target order
+        if (args.verbose or args.debug) and rank == 0:
+            err.write("km_amd: -v / -d lines are printed by single-process runs only (the ranks return rows, not node lists)\n")
         blocks = kd.find_mutation_sharded(targets, args.jellyfish_fn, params=params)
         if rank == 0:
             out.write(report.HEADER + "\n")
@@ -125,16 +129,47 @@ def main_find_mut(args, out=None, err=None):
     jf = Jellyfish(args.jellyfish_fn, cutoff=args.ratio, n_cutoff=args.count)
     out.write(report.HEADER + "\n")
     finder = BatchFinder(jf, args.steps, args.branchs, args.nodes)
+    # The reference builds every RefSeq before the first MutationFinder (km/tools/find_mutation.py:37-45):
+    # a target that is too short, has a non-ACGT base or repeats a k-mer stops the run BEFORE any row is
+    # printed.  Those errors come out of the GPU batch here, so with more than one batch the rows are
+    # held back until every batch has passed that check (up to STREAM_ABOVE targets; beyond that — some
+    # GB of text — batches are printed as they finish and such an error may follow rows already out).
+    hold = CHUNK < len(targets) <= STREAM_ABOVE
+    held = []
+    sink = out
+
+    def release():
+        for text in held:
+            out.write(text)
+        del held[:]
+
     for lo in range(0, len(targets), CHUNK):
         part = targets[lo:lo + CHUNK]
+        if hold:
+            sink = io.StringIO()
         try:
-            finder.write_rows(part, out)           # native reporting (km_report_rows), one write per batch
+            finder.write_rows(part, sink)          # native reporting (km_report_rows), one write per batch
         except NodeLimitExceeded as e:
+            if hold:
+                held.append(sink.getvalue())
+                release()                          # the rows of the earlier targets, then the reference's exit
+            out.flush()
             sys.exit(str(e))
+        except BaseException as e:
+            if hold and not getattr(e, "km_input_error", False):
+                held.append(sink.getvalue())
+                release()                          # an exception while naming a variant: the earlier rows are out
+                out.flush()
+            raise
+        if hold:
+            held.append(sink.getvalue())
         if args.verbose or args.debug:
             for t in range(len(part)):
                 _verbose_lines(part[t], finder.last_raw, t, jf.k, err)
-        out.flush()
+        if not hold:
+            out.flush()
+    release()
+    out.flush()
     out.write("#Elapsed time:" + str(time.time() - t0) + "\n")
 
 
@@ -173,6 +208,7 @@ def main_min_cov(args, out=None):
     out.write("DB\tcount\tlength\tmin\tmax\tmean\tkmer_nb\tkmer_nb_0\n")
     for db in dbs:
         res = common.get_cov(db, seq)
+        common.close(db)                 # one database in HBM at a time, as the reference holds one (min_cov.py:18-25)
         out.write("%s\t%d\t%d\t%d\t%d\t%.2f\t%d\t%d\n" % ((db,) + tuple(res)))
 
 

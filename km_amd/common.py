@@ -25,6 +25,13 @@ def _handle(db):
     return jf
 
 
+def close(db):
+    """Free the HBM table of one database opened through get_cov (a path), if it is open."""
+    jf = _OPEN.pop(db, None)
+    if jf is not None:
+        jf.db.close()
+
+
 def close_all():
     for jf in _OPEN.values():
         jf.db.close()

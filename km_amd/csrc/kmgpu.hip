@@ -581,6 +581,48 @@ extern "C" int kmjf_children_batch(kmjf_t* h, const uint64_t* kmers, uint64_t n,
   return KM_OK;
 }
 
+// ---------------------------------------------------------------------------- environment knobs
+// Read once per process.  The ones that make results INVALID (timing ablations) exist only in a
+// diagnostics build of the library (-DKM_DIAGNOSTICS, what tools/_diag.py compiles): the product
+// library cannot be talked into returning KM_OK over undelivered or partial data.
+namespace {
+struct Knobs {
+  uint32_t debug_flags = 0;     // KM_DEBUG_FLAGS      (diagnostics build) stage cuts of k_dfs / k_graph
+  int debug_deliver = 0;        // KM_DEBUG_DELIVER    (diagnostics build) skip delivery kernels / copy
+  bool zero_copy = false;       // KM_DELIVER_ZEROCOPY (diagnostics build) pack straight into pinned memory
+  int dfs_replay = 0;           // KM_DFS_REPLAY       (diagnostics build) k_dfs twice per step
+  bool epilogue = true;         // KM_EPILOGUE=0: every flagged target through k_graph (results unchanged)
+  bool seed_stamps = false;     // KM_SEED_STAMPS: in-kernel time stamps (results unchanged, slower)
+  bool host_trace = false;      // KM_TRACE_HOST: host time of the sections of km_batch_run on stderr
+  long spin_us = 0;             // KM_SPIN_US: poll the delivery event this long before sleeping on it
+};
+Knobs read_knobs() {
+  Knobs q;
+  auto num = [](const char* name, long dflt) { const char* v = getenv(name); return v ? strtol(v, nullptr, 0) : dflt; };
+#ifdef KM_DIAGNOSTICS
+  q.debug_flags = (uint32_t)num("KM_DEBUG_FLAGS", 0);
+  q.debug_deliver = (int)num("KM_DEBUG_DELIVER", 0);
+  q.zero_copy = num("KM_DELIVER_ZEROCOPY", 0) != 0;
+  q.dfs_replay = (int)num("KM_DFS_REPLAY", 0);
+#endif
+  q.epilogue = num("KM_EPILOGUE", 1) != 0;
+  q.seed_stamps = getenv("KM_SEED_STAMPS") != nullptr;
+  q.host_trace = getenv("KM_TRACE_HOST") != nullptr;
+  q.spin_us = num("KM_SPIN_US", 0);
+  return q;
+}
+const Knobs& knobs() {
+#ifdef KM_DIAGNOSTICS
+  static thread_local Knobs k;      // the diagnostics tools change the ablation flags between runs
+  k = read_knobs();
+  return k;
+#else
+  static const Knobs k = read_knobs();
+  return k;
+#endif
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------- batch
 namespace {
 
@@ -1005,8 +1047,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.fetches = reinterpret_cast<unsigned long long*>(b->d_fetches.p);
   a.g_ws = nullptr;
   a.g_stride = 0;
-  const char* dbg = getenv("KM_DEBUG_FLAGS");   // timing ablations only; results are invalid
-  a.dbg = dbg ? ((uint32_t)strtoul(dbg, nullptr, 0) & 0xFFu) : 0;
+  a.dbg = knobs().debug_flags & 0xFFu;          // timing ablations (diagnostics build only); results are invalid
 }
 
 static void fill_graph_args(km_batch* b, GraphArgs& g) {
@@ -1051,8 +1092,7 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.tref_len = (uint32_t)std::min<uint64_t>(b->d_tref.n, 0xFFFFFFFFull);
   g.g_ws = nullptr;
   g.g_stride = 0;
-  const char* dbg = getenv("KM_DEBUG_FLAGS");
-  g.dbg = dbg ? ((uint32_t)strtoul(dbg, nullptr, 0) >> 8) : 0;
+  g.dbg = knobs().debug_flags >> 8;
   if (b->graph_mode == 1) g.dbg = 1;       // duplicate check only
   if (g.dbg && !(g.dbg & 0x80u)) g.work_list = nullptr;   // every target goes through k_graph: no list
 }
@@ -1115,8 +1155,7 @@ static void fast_geometry(km_batch* b) {
   }
   // the epilogue of k_dfs answers the regular flagged targets when the graph stage is wanted in full
   // (KM_EPILOGUE=0: diagnostics, everything through k_graph as in round 2)
-  static const bool epilogue_on = !(getenv("KM_EPILOGUE") && atoi(getenv("KM_EPILOGUE")) == 0);
-  if (epilogue_on && b->graph_mode == 0 && ga.dbg == 0 && ga.work_list != nullptr) {
+  if (knobs().epilogue && b->graph_mode == 0 && ga.dbg == 0 && ga.work_list != nullptr) {
     EpiArgs e;
     memset(&e, 0, sizeof e);
     e.counters = ga.counters; e.path_pool = ga.path_pool; e.run_pool = ga.run_pool;
@@ -1199,7 +1238,7 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.blk_base = b->d_blk_base.p; oa.scan_ticket = b->d_scan_ticket.p;
   // KM_DELIVER_ZEROCOPY=1: the delivery kernels store straight into the pinned host buffer
   // (PCIe writes from the CUs, no copy command on the stream); default: device buffer + one DMA
-  static const bool zero_copy = getenv("KM_DELIVER_ZEROCOPY") && atoi(getenv("KM_DELIVER_ZEROCOPY")) != 0;
+  const bool zero_copy = knobs().zero_copy;
   unsigned char* dst = zero_copy ? b->h_out : b->d_out;
   oa.totals = reinterpret_cast<unsigned long long*>(dst + L.totals);
   oa.o_status = reinterpret_cast<uint32_t*>(dst + L.status);
@@ -1211,8 +1250,8 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.o_refmax = reinterpret_cast<uint32_t*>(dst + L.ref_max);
   oa.tail = dst + L.a_bytes;
   oa.tail_cap = b->out_cap - L.a_bytes;
-  static const int dbg_deliver = getenv("KM_DEBUG_DELIVER") ? atoi(getenv("KM_DEBUG_DELIVER")) : 0;   // timing ablations only
-  static const bool host_trace = getenv("KM_TRACE_HOST") != nullptr;   // diagnostics: host time of the calls below
+  const int dbg_deliver = knobs().debug_deliver;   // timing ablations (diagnostics build only)
+  const bool host_trace = knobs().host_trace;      // diagnostics: host time of the calls below
   auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double h0 = host_trace ? now_us() : 0;
   if (!(dbg_deliver & 2)) {
@@ -1257,7 +1296,7 @@ static double host_now_us() {
 }
 extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   if (!b) return fail(KM_E_ARG, "null argument");
-  static const bool host_trace = getenv("KM_TRACE_HOST") != nullptr;   // diagnostics: host time of the sections
+  const bool host_trace = knobs().host_trace;      // diagnostics: host time of the sections
   double ht[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ht[0] = host_trace ? host_now_us() : 0;
   HIPCHK(hipSetDevice(b->device));
@@ -1303,7 +1342,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   }
   wa.f_ws = b->d_frames.p;
   wa.stamps = nullptr;
-  if (getenv("KM_SEED_STAMPS")) {
+  if (knobs().seed_stamps) {
     int rc = b->d_stamps.alloc(16ull * (SEED_BLOCK / 64) * (b->n_items + 4));
     if (rc != KM_OK) return rc;
     wa.stamps = b->d_stamps.p;
@@ -1348,7 +1387,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     };
     // diagnostics (KM_DFS_REPLAY=1|2): k_dfs twice, the SECOND launch is the one timed — its instruction
     // cache is warm; with 2 a 1 GiB memset in between flushes L2 / Infinity Cache (data cold again)
-    static const int dfs_replay = getenv("KM_DFS_REPLAY") ? atoi(getenv("KM_DFS_REPLAY")) : 0;
+    const int dfs_replay = knobs().dfs_replay;
     if (dfs_replay) {
       launch_dfs();
       if (dfs_replay == 2) {
@@ -1621,7 +1660,7 @@ extern "C" int km_batch_sync(km_batch_t* b) {
 // thread to sleep at once (default 0: on the boxes measured a polling consumer gained nothing,
 // 0.315 against 0.312 ms per delivered step).
 static hipError_t wait_event_hot(hipEvent_t ev) {
-  static const long spin_us = getenv("KM_SPIN_US") ? atol(getenv("KM_SPIN_US")) : 0;
+  const long spin_us = knobs().spin_us;
   if (spin_us > 0) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -1654,7 +1693,7 @@ static int finish_result(km_batch* b, bool need_full) {
   const unsigned long long* T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
   for (int attempt = 0;; ++attempt) {
     HIPCHK(wait_event_hot(b->ev_out));
-    if (getenv("KM_DEBUG_DELIVER") && atoi(getenv("KM_DEBUG_DELIVER"))) {      // timing ablation: nothing valid arrived
+    if (knobs().debug_deliver) {                      // timing ablation (diagnostics build only): nothing valid arrived
       b->deliver_pending = false; b->result_ready = true;
       return KM_OK;
     }

@@ -535,6 +535,25 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
     return KM_E_ARG;
   if (in->k < 2 || in->k > 32) return KM_E_K;
   const uint32_t n = in->n_targets;
+  // The view's offset arrays against the lengths of what they index, when the caller gave them.
+  // (Round 2 lost a test process to a heap overwrite in fit_paths: a work-in-progress delivery handed
+  // over a target with variant paths but no counts, and contrib[path node] was written past a
+  // two-element vector.  The per-target checks below make such a view an error code.)
+  if (in->sizes) {
+    const km_batch_sizes_t& z = *in->sizes;
+    if (z.n_targets != n) return KM_E_ARG;
+    if (n) {
+      if (r.node_off[0] != 0 || r.node_off[n] != z.n_nodes || r.path_off[0] != 0 || r.path_off[n] != z.n_paths) return KM_E_ARG;
+      if (r.extra_off && (r.extra_off[0] != 0 || r.extra_off[n] != z.n_extra)) return KM_E_ARG;
+      if (r.run_off[0] != 0 || r.run_off[z.n_paths] != z.n_runs) return KM_E_ARG;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+      if (r.node_off[t + 1] < r.node_off[t] || r.path_off[t + 1] < r.path_off[t]) return KM_E_ARG;
+      if (r.extra_off && r.extra_off[t + 1] < r.extra_off[t]) return KM_E_ARG;
+    }
+    for (uint32_t p = 0; p < z.n_paths; ++p)
+      if (r.run_off[p + 1] < r.run_off[p]) return KM_E_ARG;
+  }
   uint64_t* row_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n + 1));
   int32_t* err = (int32_t*)malloc(sizeof(int32_t) * std::max<size_t>(1, n));
   if (!row_off || !err) { free(row_off); free(err); return KM_E_NOMEM; }
@@ -560,23 +579,39 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
           t.kmers = r.node_kmer ? r.node_kmer + r.node_off[ti] : nullptr;
           t.extra = r.node_kmer ? nullptr : r.extra_kmer + r.extra_off[ti];
           t.counts = r.node_count + r.node_off[ti];
+          // ---- this target's slice of the view must hang together before any of it is used
+          if (r.node_off[ti + 1] < r.node_off[ti] || r.path_off[ti + 1] < r.path_off[ti] ||
+              in->base_off[ti + 1] < in->base_off[ti]) { err[ti] = 5; continue; }
           t.n_nodes = (int64_t)(r.node_off[ti + 1] - r.node_off[ti]);
           t.ref_max = 0;
-          if (t.n_nodes == 0 && t.n_ref > 0) {
-            if (!r.ref_max_cov || r.ref_max_cov[ti] == 0xFFFFFFFFu) { err[ti] = 3; continue; }
+          const bool lean = t.n_nodes == 0 && t.n_ref > 0;
+          if (lean) {
+            if (!r.ref_max_cov || r.ref_max_cov[ti] == 0xFFFFFFFFu) { err[ti] = 5; continue; }   // counts missing
             t.counts = nullptr;                      // bare-reference target, delivered lean
             t.ref_max = r.ref_max_cov[ti];
             t.n_nodes = t.n_ref;
           }
+          if (t.n_nodes < t.n_ref || (int64_t)t.seq_len < t.n_ref + t.k - 1) { err[ti] = 5; continue; }
+          if (!r.node_kmer) {
+            if (r.extra_off[ti + 1] < r.extra_off[ti] ||
+                (int64_t)(r.extra_off[ti + 1] - r.extra_off[ti]) != t.n_nodes - t.n_ref) { err[ti] = 5; continue; }
+          }
           const uint32_t p0 = r.path_off[ti], p1 = r.path_off[ti + 1];
           t.paths.resize(p1 - p0);
           t.min_cov.assign(r.path_min_cov + p0, r.path_min_cov + p1);
-          for (uint32_t p = p0; p < p1; ++p) {
+          bool consistent = true;
+          for (uint32_t p = p0; p < p1 && consistent; ++p) {
             Path& path = t.paths[p - p0];
             path.clear();
-            for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q)
+            if (r.run_off[p + 1] < r.run_off[p]) { consistent = false; break; }
+            for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
+              // every node of a path is one of this target's nodes (fit_paths indexes by it)
+              if ((int64_t)r.run_start[q] + (int64_t)r.run_len[q] > t.n_nodes) { consistent = false; break; }
               for (uint32_t j = 0; j < r.run_len[q]; ++j) path.push_back((int64_t)r.run_start[q] + j);
+            }
           }
+          if (!consistent) { err[ti] = 5; continue; }
+          if (lean && !(t.paths.size() == 1 && is_reference(t.paths[0], t.n_ref))) { err[ti] = 5; continue; }
           g_tie = false;
           err[ti] = target_rows(t, in->db_name ? in->db_name : "", &rows);
           if (err[ti]) continue;

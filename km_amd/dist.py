@@ -5,8 +5,9 @@ The reference runs the loop of km/tools/find_mutation.py:47-58 serially, and its
 Leucegene-scale use is a shell loop over samples (example/run_leucegene.sh:29-35).  Every
 (target x sample) unit is independent, so there are two shardings:
 
-* :func:`find_mutation_sharded` — ONE database, targets sharded in contiguous blocks
-  (BASELINE config 4).  The database crosses the links once, as its compact RECORDS
+* :func:`find_mutation_sharded` — ONE database, targets sharded (:func:`shard_plan`: contiguous
+  blocks for a small input, 8 192-target chunks dealt round-robin for a large catalog;
+  BASELINE config 4).  The database crosses the links once, as its compact RECORDS
   (12 B per k-mer, one packed buffer), not as the sparse 100 B-per-k-mer table: every rank
   builds its own HBM table from the received records with the device insert kernels
   (``kmjf_upload_from_device``, 0.05 s per 100 M k-mers), which is 8x less link traffic than
@@ -85,6 +86,20 @@ def shard_range(n, rank, world):
     base, extra = divmod(n, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+CHUNK = 8192          # targets per GPU batch (km_amd.cli.CHUNK is the same number)
+
+
+def shard_plan(n, world, chunk=CHUNK):
+    """How `n` targets are dealt to `world` ranks: a list of (lo, hi, rank) pieces covering [0, n) in
+    order.  A small input (at most one chunk per rank) is cut into `world` contiguous blocks
+    (:func:`shard_range`); a large catalog into successive `chunk`-target pieces dealt round-robin,
+    so that every rank works through the same number of same-sized batches whatever clusters in the
+    input (long walks cluster by locus) and the ranks finish together."""
+    if n <= chunk * world:
+        return [shard_range(n, r, world) + (r,) for r in range(world) if shard_range(n, r, world)[1] > shard_range(n, r, world)[0]]
+    return [(lo, min(n, lo + chunk), (lo // chunk) % world) for lo in range(0, n, chunk)]
 
 
 def broadcast_records(keys, counts, k, canonical, device, src=0):
@@ -169,7 +184,11 @@ def hip_analyse(db_name, params=None, device=None):
         torch.cuda.synchronize()
         jf = Jellyfish(db_name, cutoff=prm["ratio"], n_cutoff=prm["count"], device=dev, db=db)
         finder = BatchFinder(jf, prm["steps"], prm["branchs"], prm["nodes"])
-        return finder.rows(list(my_targets)) if my_targets else []
+        my_targets = list(my_targets)
+        rows = []
+        for lo in range(0, len(my_targets), CHUNK):          # one GPU batch per chunk, the workspace is reused
+            rows.extend(finder.rows(my_targets[lo:lo + CHUNK]))
+        return rows
 
     return analyse
 
@@ -192,12 +211,13 @@ def hip_run_sample(targets, params=None, device=None):
 
 
 # ------------------------------------------------------------------------- orchestration
-def find_mutation_sharded(targets, db_path, analyse=None, load_records=None, params=None):
+def find_mutation_sharded(targets, db_path, analyse=None, load_records=None, params=None, chunk=None):
     """Target-sharded find_mutation.  `targets`: list of (name, seq) known to every rank; rank 0
     reads the database (`load_records(db_path) -> keys, counts, k, canonical`; default: the
     native host reader), broadcasts its records once, every rank calls
     `analyse(d_keys, d_cnts, n, k, canonical, my_targets) -> list (rows per target)` on its shard
-    (default: :func:`hip_analyse`); rank 0 returns all of them in target order, other ranks None."""
+    (default: :func:`hip_analyse`); rank 0 returns all of them in target order, other ranks None.
+    `chunk`: piece size of :func:`shard_plan` (default 8 192 targets)."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -214,9 +234,42 @@ def find_mutation_sharded(targets, db_path, analyse=None, load_records=None, par
         keys = counts = None
         k = canonical = 0
     d_keys, d_cnts, n, k, canonical = broadcast_records(keys, counts, k, canonical, device)
-    lo, hi = shard_range(len(targets), rank, world)
-    rows = analyse(d_keys, d_cnts, n, k, canonical, targets[lo:hi])
-    return gather_in_order(rows)
+    # every rank takes its pieces of the plan, in order, as ONE call of `analyse` (one table build);
+    # whatever it raises travels to rank 0 with the gather instead of leaving the other ranks waiting
+    # in it: the error of the earliest target wins there, as in a serial run
+    plan = shard_plan(len(targets), world, chunk or CHUNK)
+    mine = [t for lo, hi, r in plan if r == rank for t in targets[lo:hi]]
+    try:
+        payload = ("rows", analyse(d_keys, d_cnts, n, k, canonical, mine))
+    except BaseException as exc:             # noqa: BLE001 — re-raised on rank 0
+        if isinstance(exc, (KeyboardInterrupt, SystemExit)):
+            raise
+        payload = ("error", exc)
+    if world == 1:
+        if payload[0] == "error":
+            raise payload[1]
+        return payload[1]
+    bucket = [None] * world if rank == 0 else None
+    try:
+        dist.gather_object(payload, bucket, dst=0)
+    except Exception:                          # an exception that does not pickle: send its text
+        dist.gather_object(("error", RuntimeError(repr(payload[1]))), bucket, dst=0)
+    if rank != 0:
+        return None
+    out = [None] * len(targets)
+    taken = [0] * world
+    first_error = None
+    for lo, hi, r in plan:
+        kind, data = bucket[r]
+        if kind == "error":
+            if first_error is None:
+                first_error = data
+            break                                # nothing after the first failing piece is used
+        out[lo:hi] = data[taken[r]:taken[r] + (hi - lo)]
+        taken[r] += hi - lo
+    if first_error is not None:
+        raise first_error
+    return out
 
 
 def find_mutation_samples(db_paths, run_sample=None, targets=None, params=None):

@@ -19,6 +19,11 @@ class NodeLimitExceeded(Exception):
         self.max_node = max_node
         super().__init__("ERROR: Node query count limit exceeded: max=%d" % max_node)
 
+    def __reduce__(self):
+        # pickle rebuilds an exception from its args (the formatted message) by default; the ranks of
+        # km_amd.dist gather row lists that may hold this one
+        return (NodeLimitExceeded, (self.max_node,))
+
 
 def repeated_kmer_message(seq, name, k):
     """The ValueError text of km/utils/common.py:55-59 for the first repeated k-mer."""
@@ -59,15 +64,21 @@ class BatchFinder:
         # RefSeq construction comes first for every target in the reference
         # (km/tools/find_mutation.py:37-45): its errors pre-empt all output
         k = self.jf.k
-        for t, st in enumerate(raw["status"].tolist()):
-            if st == _lib.T_EMPTY:
-                raise AssertionError("target %s is shorter than k=%d" % (names[t], k))
-            if st == _lib.T_BAD_BASE:
-                raise ValueError("target %s contains characters other than ACGT" % names[t])
-            if st == _lib.T_REPEAT_KMER:
-                raise ValueError(repeated_kmer_message(seqs[t], names[t], k))
-            if st == _lib.T_INTERNAL:
-                raise RuntimeError("libkmgpu: internal workspace overflow on target %s" % names[t])
+        bad = np.nonzero(np.isin(raw["status"], (_lib.T_EMPTY, _lib.T_BAD_BASE, _lib.T_REPEAT_KMER, _lib.T_INTERNAL)))[0]
+        if bad.size == 0:
+            return
+        t = int(bad[0])
+        st = int(raw["status"][t])
+        if st == _lib.T_EMPTY:
+            exc = AssertionError("target %s is shorter than k=%d" % (names[t], k))
+        elif st == _lib.T_BAD_BASE:
+            exc = ValueError("target %s contains characters other than ACGT" % names[t])
+        elif st == _lib.T_REPEAT_KMER:
+            exc = ValueError(repeated_kmer_message(seqs[t], names[t], k))
+        else:
+            exc = RuntimeError("libkmgpu: internal workspace overflow on target %s" % names[t])
+        exc.km_input_error = True            # raised before any row of its batch (km_amd.cli holds rows back for it)
+        raise exc
 
     def rows(self, targets, db_name=None):
         """targets: list of (name, seq).  The TSV rows of every target through the native

@@ -5,8 +5,11 @@ arrays own every in/out buffer.  There is NO CPU fallback — if the HIP library
 is missing or cannot be loaded, :func:`load` raises.
 """
 
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -71,34 +74,74 @@ class ReportIn(C.Structure):
     """km_report_in_t (include/kmgpu.h)."""
     _fields_ = [("n_targets", C.c_uint32), ("bases", C.c_void_p), ("base_off", C.c_void_p),
                 ("names", C.POINTER(C.c_char_p)), ("db_name", C.c_char_p), ("k", C.c_int32),
-                ("reserved", C.c_int32), ("res", C.POINTER(BatchOut))]
+                ("reserved", C.c_int32), ("res", C.POINTER(BatchOut)), ("sizes", C.POINTER(BatchSizes))]
 
 
 _lib = None
+
+# Live native handles, closed at interpreter exit while the HIP runtime is still up: batches first
+# (they reference their database), then databases.  Without this a handle that is still alive when
+# Python tears its modules down is destroyed by __del__ in arbitrary order, possibly after the HIP
+# runtime has unloaded its state (round 2: a SIGSEGV inside __cxa_finalize under rocprofv3).
+_LIVE_BATCHES = weakref.WeakSet()
+_LIVE_DATABASES = weakref.WeakSet()
+
+
+def close_all_handles():
+    for b in list(_LIVE_BATCHES):
+        try:
+            b.close()
+        except Exception:
+            pass
+    for d in list(_LIVE_DATABASES):
+        try:
+            d.close()
+        except Exception:
+            pass
+
+
+atexit.register(close_all_handles)
 
 
 def _share_hip_runtime_with_torch():
     """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same
     SONAME as /opt/rocm's): whichever is loaded first serves both libkmgpu.so and torch, and torch
-    finds no GPU when it is the system one.  If torch is installed but not imported yet (a later
-    `import torch` — km_amd.dist, bench.py — must keep working), load ITS runtime first; without
-    torch, or with KM_HIP_RUNTIME=system, libkmgpu.so uses the ROCm installation's."""
+    finds no GPU when it is the system one.  So when torch is installed but not imported yet (a later
+    `import torch` — km_amd.dist, bench.py — must keep working) ITS runtime is loaded first.
+    KM_HIP_RUNTIME=system keeps the ROCm installation's (a process that will never import torch: a
+    single-GPU `km find_mutation`, a C consumer); KM_HIP_RUNTIME=torch insists on torch's and fails
+    loudly without it.  Returns a short description of what was bound (KM_VERBOSE_LOAD=1 prints it)."""
     import importlib.util
-    import sys
-    if "torch" in sys.modules or os.environ.get("KM_HIP_RUNTIME", "") == "system":
-        return
+    want = os.environ.get("KM_HIP_RUNTIME", "")
+    if "torch" in sys.modules:
+        return "torch already imported: its HIP runtime serves libkmgpu.so"
+    if want == "system":
+        return "system HIP runtime (KM_HIP_RUNTIME=system)"
     try:
         spec = importlib.util.find_spec("torch")
     except Exception:
         spec = None
     if spec is None or not spec.origin:
-        return
+        if want == "torch":
+            raise ImportError("km_amd: KM_HIP_RUNTIME=torch but torch is not installed")
+        return "system HIP runtime (no torch installed)"
     cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    if not os.path.exists(cand):
+        if want == "torch":
+            raise ImportError("km_amd: KM_HIP_RUNTIME=torch but %s does not exist" % cand)
+        return "system HIP runtime (torch ships no libamdhip64.so)"
+    try:
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        if want == "torch":
+            raise ImportError("km_amd: cannot load %s: %s" % (cand, exc))
+        sys.stderr.write("km_amd: could not preload torch's HIP runtime (%s): %s — libkmgpu.so binds the system one; "
+                         "a later `import torch` may then find no GPU (KM_HIP_RUNTIME=system silences this)\n" % (cand, exc))
+        return "system HIP runtime (preload of torch's failed)"
+    return "torch's bundled HIP runtime %s (KM_HIP_RUNTIME=system to use the ROCm installation's)" % cand
+
+
+HIP_RUNTIME_BOUND = None
 
 
 def load():
@@ -109,7 +152,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("km_amd: %s is missing — run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (there is no CPU fallback)" % LIB_PATH)
-    _share_hip_runtime_with_torch()
+    global HIP_RUNTIME_BOUND
+    HIP_RUNTIME_BOUND = _share_hip_runtime_with_torch()
+    if os.environ.get("KM_VERBOSE_LOAD"):
+        sys.stderr.write("km_amd: %s; library %s\n" % (HIP_RUNTIME_BOUND, LIB_PATH))
     lib = C.CDLL(LIB_PATH)
     vp, cp = C.c_void_p, C.c_char_p
     u32, u64, i32, i64, dbl = C.c_uint32, C.c_uint64, C.c_int, C.c_int64, C.c_double
@@ -206,6 +252,7 @@ class Database:
     def __init__(self, handle):
         self._h = handle
         self._lib = load()
+        _LIVE_DATABASES.add(self)
 
     @classmethod
     def open(cls, path):
@@ -318,6 +365,7 @@ class Batch:
         check(self._lib.km_batch_create(db._h, C.byref(self.params), int(max_targets),
                                         int(max_total_bases), C.byref(self._b)))
         self.n_targets = 0
+        _LIVE_BATCHES.add(self)
 
     def close(self):
         if self._b is not None and self._b.value:
@@ -374,6 +422,8 @@ class Batch:
         return out.reshape(-1, 16)
 
     def sizes(self):
+        """Sizes of a FULL delivery.  After a lean result() this (like fetch()) delivers again into the
+        same pinned buffer: arrays returned by that result() must not be used afterwards."""
         s = BatchSizes()
         check(self._lib.km_batch_sizes(self._b, C.byref(s)))
         return s
@@ -473,7 +523,8 @@ def expand_path(res, p):
 
 REPORT_ERRORS = {1: IndexError("list index out of range"),
                  2: Exception("mutation identification could be incorrect"),
-                 3: AssertionError(), 4: ValueError("min() arg is an empty sequence")}
+                 3: AssertionError(), 4: ValueError("min() arg is an empty sequence"),
+                 5: RuntimeError("km_report_rows: the result view of this target is inconsistent")}
 
 
 def _python_rows(res, t, name, seq, k, db_name):
@@ -551,6 +602,14 @@ def report_text(res, names, seqs, k, db_name, packed=None):
     inp.db_name = str(db_name).encode()
     inp.k = int(k)
     inp.res = C.pointer(out)
+    # the lengths of the arrays, so that the library checks every offset against them first
+    sz = BatchSizes()
+    sz.n_targets = n
+    sz.n_nodes = int(np.asarray(res["node_count"]).size)
+    sz.n_paths = int(np.asarray(res["path_min_cov"]).size)
+    sz.n_runs = int(np.asarray(res["run_start"]).size)
+    sz.n_extra = int(np.asarray(res["extra_kmer"]).size) if "extra_kmer" in res else 0
+    inp.sizes = C.pointer(sz)
     text = C.c_void_p()
     row_off = C.POINTER(C.c_uint64)()
     err = C.POINTER(C.c_int32)()

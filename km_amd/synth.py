@@ -61,7 +61,7 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
               variant_frac=0.30, variants_per_target=(1, 1), vaf=(0.1, 0.6),
               kinds=("snv", "ins", "del", "dup"), noise_frac=0.01, noise_counts=(2, 5),
               cov=(50, 2000), hom_frac=0.0, branch_noise_frac=0.0, name=None,
-              exact_pad=True, canonical=True, **_):
+              exact_pad=True, canonical=True, heavy_frac=0.0, **_):
     """Build targets + (keys, counts).  Returns dict(targets=uint8[n,L] codes,
     names, keys uint64 (canonical, distinct), counts uint32, k)."""
     rng = np.random.default_rng(seed)
@@ -76,8 +76,14 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
     has_var = rng.random(n_targets) < variant_frac
     for t in np.nonzero(has_var)[0]:
         nv = int(rng.integers(variants_per_target[0], variants_per_target[1] + 1))
+        # heavy_frac: that share of the variant targets carries 3-5 tandem duplications instead (long
+        # walks: the large tier of k_dfs / k_graph).  Nothing is drawn for it when it is 0, so that the
+        # cases the goldens were made from stay what they are.
+        heavy = bool(heavy_frac) and rng.random() < heavy_frac
+        if heavy:
+            nv = int(rng.integers(3, 6))
         for _v in range(nv):
-            kind = kinds[int(rng.integers(0, len(kinds)))]
+            kind = "dup" if heavy else kinds[int(rng.integers(0, len(kinds)))]
             mut, lo, hi = _mutate(rng, rows[t], kind, k)
             f = float(rng.uniform(vaf[0], vaf[1]))
             if hom_frac and rng.random() < hom_frac:

@@ -229,3 +229,89 @@ def test_native_rows_lean_zero_coverage_reference():
     want = kmlib.report_rows(raw, ["zero"], [seq], k, "mem.jf")
     assert "nan" in want[0][0].split("\t")[5]
     assert kmlib.report_rows(_as_delivery(raw, True), ["zero"], [seq], k, "mem.jf") == want
+
+
+def _dump_view(path, raw, seqs, k):
+    """The arrays of a delivery view (extra_kmer form, ref_max_cov set for bare-reference targets) in
+    the plain binary layout tests/host/report_views.cpp reads."""
+    n = len(seqs)
+    n_ref = raw["n_ref"].astype(np.int64)
+    noff = raw["node_off"].astype(np.int64)
+    extra, xoff, ref_max = [], [0], []
+    for t in range(n):
+        extra += raw["node_kmer"][noff[t] + n_ref[t]:noff[t + 1]].tolist()
+        xoff.append(len(extra))
+        npaths = int(raw["path_off"][t + 1] - raw["path_off"][t])
+        bare = npaths == 1 and noff[t + 1] - noff[t] == n_ref[t] and int(raw["path_len"][raw["path_off"][t]]) == n_ref[t]
+        ref_max.append(int(raw["node_count"][noff[t]:noff[t] + n_ref[t]].max()) if bare else 0xFFFFFFFF)
+    blob = "".join(seqs).encode()
+    boff = np.cumsum([0] + [len(s_) for s_ in seqs]).astype(np.uint64)
+    with open(path, "wb") as fh:
+        fh.write(np.array([n, k], dtype=np.uint32).tobytes())
+        for arr, dt in ((np.frombuffer(blob, dtype=np.uint8), np.uint8), (boff, np.uint64), (raw["status"], np.uint32),
+                        (raw["n_ref"], np.uint32), (raw["node_off"], np.uint64), (raw["node_count"], np.uint32),
+                        (np.array(xoff), np.uint64), (np.array(extra), np.uint64), (raw["path_off"], np.uint32),
+                        (raw["run_off"], np.uint64), (raw["run_start"], np.uint32), (raw["run_len"], np.uint32),
+                        (raw["path_min_cov"], np.uint32), (np.array(ref_max), np.uint32)):
+            a = np.ascontiguousarray(arr, dtype=dt)
+            fh.write(np.uint64(a.size).tobytes())
+            fh.write(a.tobytes())
+
+
+def _synthetic_view(n_targets=60):
+    case = synth.make_case(n_targets=n_targets, length=220, k=21, n_keys=4000, seed=9123, variant_frac=0.6,
+                           variants_per_target=(1, 2), cov=(60, 500))
+    db = ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                   records={"k": 21, "canonical": True, "keys": case["keys"], "counts": case["counts"]})
+    results, seqs = [], []
+    for row, name in zip(case["targets"], case["names"]):
+        seq = km.decode(row)
+        results.append(ko.analyse_target(seq, name, db))
+        seqs.append(seq)
+    return _raw_from_oracle(results), seqs, results
+
+
+def test_inconsistent_views_are_error_codes_under_the_sanitizers(tmp_path):
+    """csrc/report.cpp built for the CPU with AddressSanitizer + UBSan (tests/host/report_views.cpp): the full
+    and the lean view give the same rows; views whose offsets, node indices or counts do not hang together
+    — among them the one that overwrote the heap of a test process in round 2 (a target with variant paths
+    delivered without counts) — come back as KM_E_ARG / err 5, with no out-of-bounds access on the way."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "report_views")
+    subprocess.check_call([gxx, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-o", exe,
+                           os.path.join(HERE, "host", "report_views.cpp"),
+                           os.path.join(root, "km_amd", "csrc", "report.cpp")])
+    raw, seqs, results = _synthetic_view()
+    assert any(len(r["paths"]) > 1 for r in results) and any(len(r["paths"]) == 1 for r in results)
+    view = str(tmp_path / "view.bin")
+    _dump_view(view, raw, seqs, 21)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    proc = subprocess.run([exe, view], capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0 and "VIEWS OK" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in proc.stderr and "runtime error" not in proc.stderr, proc.stderr[-3000:]
+
+
+def test_inconsistent_view_through_the_binding():
+    """The same through ctypes and the product library: err 5 turns into an exception for that target only,
+    lengths that do not match the offsets into KM_E_ARG for the call."""
+    raw, seqs, results = _synthetic_view(24)
+    names = [r["name"] for r in results]
+    good = kmlib.report_rows(raw, names, seqs, 21, "view.jf")
+    tv = next(t for t, r in enumerate(results) if len(r["paths"]) > 1)
+    bad = dict(raw)
+    bad["run_start"] = raw["run_start"].copy()
+    bad["run_start"][int(raw["run_off"][int(raw["path_off"][tv]) + 1])] += 50000
+    rows = kmlib.report_rows(bad, names, seqs, 21, "view.jf")
+    assert isinstance(rows[tv], RuntimeError)
+    assert all(rows[t] == good[t] for t in range(len(names)) if t != tv)
+    bad = dict(raw)
+    bad["node_off"] = raw["node_off"].copy()
+    bad["node_off"][-1] += 3
+    with pytest.raises(kmlib.KmError):
+        kmlib.report_rows(bad, names, seqs, 21, "view.jf")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # which part of the delivery costs the pipelined step?  KM_DEBUG_DELIVER: 1 = no copy, 2 = no kernels
 # (timing ablations; nothing valid arrives); and the number of hardware queues the streams share
+export KM_LIBRARY=$(python3 tools/_diag.py)     # KM_DEBUG_DELIVER exists in the diagnostics build only
 run() {
   env "$@" python3 bench.py --steps 40 --warmup 4 --no-cpu --only-step --check 0 --cache /tmp/kmc 2>/dev/null | python3 -c "
 import json,sys

@@ -9,6 +9,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _diag
+    _diag.build()                   # KM_DFS_REPLAY exists in the diagnostics build only
     import numpy as np
     from km_amd import lib as kmlib, synth
     T, L, K = 10000, 500, 31

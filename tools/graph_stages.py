@@ -7,6 +7,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: E402
+
+_diag.build()                       # KM_DEBUG_FLAGS exists in the diagnostics build only
 from km_amd import lib as kmlib, synth  # noqa: E402
 
 n_keys = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
