@@ -25,6 +25,7 @@ under "config4_strong".
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import socket
@@ -344,6 +345,35 @@ def hard_workload(args, case, dev_index, stream, T, n_fl):
     return out
 
 
+def dump_case(case, path):
+    """The workload as km_amd/kmclient (tools/kmclient.cpp) reads it."""
+    os.makedirs(path, exist_ok=True)
+    np.save(os.path.join(path, "keys.npy"), np.ascontiguousarray(case["keys"], dtype=np.uint64))
+    np.save(os.path.join(path, "counts.npy"), np.ascontiguousarray(case["counts"], dtype=np.uint32))
+    np.save(os.path.join(path, "targets.npy"), np.ascontiguousarray(case["targets"], dtype=np.uint8))
+
+
+def c_abi_end_to_end(case, args, n_fl):
+    """`end_to_end_c_abi`: host strings in -> TSV text out with no interpreter between the calls — the C++
+    consumer of include/kmgpu.h (tools/kmclient.cpp, mode e2e) run as a child process on the same workload:
+    km_batch_set_targets of fresh strings every step, walk + path search, lean delivery, km_report_rows on a
+    second thread while the next batches run."""
+    import tempfile
+    client = os.path.join(ROOT, "km_amd", "kmclient")
+    if not os.path.exists(client):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        dump_case(case, td)
+        p = subprocess.run([client, "e2e", td, str(args.steps), str(max(args.warmup, n_fl)), str(n_fl), "3"],
+                           capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        return {"error": p.stderr[-500:]}
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    res["value"] = res["targets_per_s_best"]
+    res["unit"] = "targets/s"
+    return res
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -384,6 +414,11 @@ def main():
                     help="KM_RUN_SERIAL on every run: each kernel alone on the GPU, one stream (the command "
                          "behind profiles/*kernel_stats.csv: rocprofv3 then times the kernels as the roofline "
                          "section does)")
+    ap.add_argument("--dump-case", default="",
+                    help="write the workload (keys.npy, counts.npy, targets.npy) for km_amd/kmclient into this directory and exit")
+    ap.add_argument("--timeline", action="store_true",
+                    help="run the warm-up and the pipelined lean timed region only, then exit (the program behind the "
+                         "kernel + memory-copy timeline of tools/collect_evidence.sh)")
     ap.add_argument("--no-hard", dest="hard", action="store_false",
                     help="skip the second workload (config4_hard: several variants per target, branch noise, large-tier walks)")
     ap.add_argument("--repeats", type=int, default=5,
@@ -413,22 +448,46 @@ def main():
     t_gen = time.perf_counter()
     case = load_case(args, T * n_fl) if rank == 0 else None
     t_gen = time.perf_counter() - t_gen
+    if args.dump_case and rank == 0:
+        dump_case(case, args.dump_case)
+        return
     cpu = None
-    import torch                      # before libkmgpu.so: one HIP runtime per process (torch's);
-    import torch.distributed as dist  # importing torch does not touch the GPU
+    # N = 1: no PyTorch in this process.  libkmgpu.so is then served by the ROCm installation's HIP runtime, as
+    # it is for any C consumer of include/kmgpu.h (km_amd/kmclient), not by the older one bundled in the torch
+    # wheel — measured: 0.25 against 0.29 ms per pipelined step.  N > 1 needs torch.distributed (RCCL) and with
+    # it torch's runtime; KM_BENCH_TORCH=1 forces that path at N = 1 too.
+    use_torch = world > 1 or os.environ.get("KM_BENCH_TORCH") == "1"
+    torch = dist = None
+    if use_torch:
+        import torch                      # before libkmgpu.so: one HIP runtime per process (torch's);
+        import torch.distributed as dist  # importing torch does not touch the GPU
+    else:
+        os.environ.setdefault("KM_HIP_RUNTIME", "system")
     if rank == 0:
         import __graft_entry__ as ge
         ge.build()
         if not args.no_cpu and world == 1:
             cpu = cpu_baseline(case, min(args.cpu_sample, T))
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    from km_amd import lib as kmlib
+    from km_amd import synth
     if args.one_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    bdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
+    if use_torch:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        bdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
+        device_sync = torch.cuda.synchronize
+    else:
+        n_dev = C.c_int(0)
+        if kmlib.load().km_device_count(C.byref(n_dev)) != 0 or n_dev.value < 1:
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        dev = bdev = None
+
+        def device_sync():
+            kmlib.device_sync(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -438,59 +497,57 @@ def main():
             dist.init_process_group(args.backend)
         dist.barrier()
     # which ranks and devices take part (so that a driver can confirm N ranks on N devices)
-    ranks_seen = {"world_size": world, "backend": args.backend if world > 1 else None,
-                  "devices": [int(torch.cuda.current_device())]}
+    ranks_seen = {"world_size": world, "backend": args.backend if world > 1 else None, "devices": [local_rank],
+                  "hip_runtime": None}
     if world > 1:
         mine = torch.tensor([rank, int(torch.cuda.current_device())], dtype=torch.int64, device=bdev)
         seen = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(seen, mine)
         ranks_seen["devices"] = [int(x[1].item()) for x in sorted(seen, key=lambda v: int(v[0].item()))]
         ranks_seen["world_size"] = int(dist.get_world_size())
-    from km_amd import dist as kd
-    from km_amd import lib as kmlib
-    from km_amd import synth
+    ranks_seen["hip_runtime"] = kmlib.HIP_RUNTIME_BOUND
 
-    # ---- table: records to HBM, ONE broadcast over RCCL, local build on every GPU ------------
+    # ---- table: records to HBM (N > 1: ONE broadcast over RCCL), local build on every GPU --------------
     t_up = time.perf_counter()
-    d_keys, d_cnts, n_rec, _k, _canon = kd.broadcast_records(
-        case["keys"] if rank == 0 else None, case["counts"] if rank == 0 else None, K, True, bdev)
-    if rank == 0:
-        bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(bdev)
+    if use_torch:
+        from km_amd import dist as kd
+        d_keys, d_cnts, n_rec, _k, _canon = kd.broadcast_records(
+            case["keys"] if rank == 0 else None, case["counts"] if rank == 0 else None, K, True, bdev)
+        if rank == 0:
+            bases_all = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()).to(bdev)
+        else:
+            bases_all = torch.empty((T * n_fl, args.length), dtype=torch.uint8, device=bdev)
+        if world > 1:
+            dist.broadcast(bases_all, 0)
+        d_keys, d_cnts, bases_all = d_keys.to(dev).contiguous(), d_cnts.to(dev).contiguous(), bases_all.to(dev)
+        device_sync()
+        t_bcast = time.perf_counter() - t_up
+        t_build = time.perf_counter()
+        db = kmlib.Database.empty(K, True)
+        stream = torch.cuda.current_stream().cuda_stream
+        db.upload_from_device(local_rank, d_keys.data_ptr(), d_cnts.data_ptr(), n_rec, stream)
+        device_sync()
+        t_build = time.perf_counter() - t_build
+        del d_keys, d_cnts
+        torch.cuda.empty_cache()
     else:
-        bases_all = torch.empty((T * n_fl, args.length), dtype=torch.uint8, device=bdev)
-    if world > 1:
-        dist.broadcast(bases_all, 0)
-    d_keys, d_cnts, bases_all = d_keys.to(dev).contiguous(), d_cnts.to(dev).contiguous(), bases_all.to(dev)
-    torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - t_up
-    t_build = time.perf_counter()
-    db = kmlib.Database.empty(K, True)
-    stream = torch.cuda.current_stream().cuda_stream
-    db.upload_from_device(local_rank, d_keys.data_ptr(), d_cnts.data_ptr(), n_rec, stream)
-    torch.cuda.synchronize()
-    t_build = time.perf_counter() - t_build
+        stream = None
+        n_rec = int(len(case["keys"]))
+        bases_host = np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].copy()
+        db = kmlib.Database.from_records(case["keys"], case["counts"], K)
+        t_bcast = 0.0
+        t_build = time.perf_counter()
+        db.upload(local_rank)                              # records H2D + the device-side table build
+        t_build = time.perf_counter() - t_build
     info = db.info
     n_probe = int(min(n_rec, T * (args.length - K + 1)))
-    d_probe = d_keys[torch.randperm(n_rec, device=dev)[:n_probe]].contiguous() if rank == 0 else None
-    del d_keys, d_cnts
-    torch.cuda.empty_cache()
+    probe_keys = None
+    if rank == 0:
+        sel = np.random.default_rng(12345).choice(n_rec, size=n_probe, replace=False)
+        probe_keys = np.ascontiguousarray(case["keys"][sel])
 
     # ---- the box's large-copy bandwidth (device-to-device), beside the 8 TB/s spec -------------
-    d2d = None
-    if rank == 0:
-        a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        b_ = torch.empty_like(a_)
-        b_.copy_(a_)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            b_.copy_(a_)
-        e1.record()
-        torch.cuda.synchronize()
-        d2d = 2 * 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write
-        del a_, b_
-        torch.cuda.empty_cache()
+    d2d = kmlib.device_copy_GBs(local_rank, 1 << 30, 10) if rank == 0 else None      # read + write
 
     # ---- workspaces: `inflight` of them, each with its own HIP stream and its OWN target set ---
     # (weak scaling: every rank steps through the same n_fl sets, rotated by its rank)
@@ -501,9 +558,12 @@ def main():
     for q in range(n_fl):
         bq = kmlib.Batch(db, ratio=0.05, count=5, max_stack=500, max_break=10, max_node=10000,
                          max_targets=T, max_total_bases=T * args.length)
-        bq.set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
+        if use_torch:
+            bq.set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
+        else:
+            bq.set_targets_packed(bases_host[set_ids[q] * T:(set_ids[q] + 1) * T].reshape(-1), offsets)
         batches.append(bq)
-    torch.cuda.synchronize()
+    device_sync()
     stages = kmlib.KM_STAGE_WALK | (0 if args.walk_only else kmlib.KM_STAGE_GRAPH) | (kmlib.KM_RUN_SERIAL if args.serial else 0)
     if args.hipgraph:
         stages |= kmlib.KM_RUN_HIPGRAPH
@@ -520,7 +580,7 @@ def main():
         instead of ~50 (tools/launch_cost.py) and the GPU runs dry."""
         if wait and not args.py_loop:
             kmlib.pump(batches, tstreams, n_steps, flags)
-            torch.cuda.synchronize()
+            device_sync()
             return
         for i in range(n_steps):
             q = i % n_fl
@@ -530,7 +590,7 @@ def main():
         if wait:
             for q in range(min(n_fl, n_steps)):
                 batches[q].wait_result()
-        torch.cuda.synchronize()
+        device_sync()
 
     # ---- warm-up ---------------------------------------------------------------------------
     pipeline(max(n_fl, args.warmup), deliver, True)
@@ -543,7 +603,7 @@ def main():
     def timed(flags, wait):
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
         t0 = time.perf_counter()
         pipeline(args.steps, flags, wait)
         if world > 1:
@@ -559,6 +619,20 @@ def main():
         vs = [bq.result() for bq in batches]
         return vs, float(np.mean([sum(v[x].nbytes for x in v if isinstance(v[x], np.ndarray)) for v in vs]))
 
+    if args.timeline:
+        dts = [timed(deliver, True) for _ in range(max(1, args.repeats))]
+        if rank == 0:
+            print(json.dumps({"timeline_only": True, "ms_per_step": float(np.median(dts)) / args.steps * 1e3,
+                              "steps": args.steps, "repeats": len(dts), "batches_in_flight": n_fl}), flush=True)
+        for bq in batches:
+            bq.close()
+        for st_ in tstreams:
+            kmlib.stream_destroy(st_)
+        db.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0)
     # full delivery first (every node count crosses PCIe), then the lean one that `value` reports
     pipeline(n_fl, deliver_full, True)
     dt_full = timed(deliver_full, True)
@@ -589,7 +663,7 @@ def main():
     # ---- one step at a time (no pipelining), with and without delivery -------------------------
     batch = batches[0]
     st0 = tstreams[0]
-    torch.cuda.synchronize()
+    device_sync()
     t1 = time.perf_counter()
     for i in range(args.steps):
         batch.run(deliver, st0)
@@ -628,7 +702,7 @@ def main():
         for q in range(n_fl):
             lo = set_ids[q] * T + rank * Ts
             batches[q].set_targets_dev(bases_all[lo:lo + Ts].data_ptr(), offs_s, stream)
-        torch.cuda.synchronize()
+        device_sync()
         pipeline(n_fl, deliver, True)
         dts = timed(deliver, True)
         strong = {"targets_total": Ts * world, "targets_per_gpu": Ts, "ms_per_step": dts / args.steps * 1e3,
@@ -662,6 +736,12 @@ def main():
         e2e = {"targets": n_e, "seconds": time.perf_counter() - t_e}
         e2e["rows"] = sink.getvalue().count("\n")
         e2e["targets_per_s"] = n_e / e2e["seconds"]
+
+    # ---- the same end to end through the C-ABI alone (a C++ consumer, no Python between the calls)
+    e2e_c = None
+    if rank == 0 and world == 1 and args.e2e > 0 and not args.only_step:
+        e2e_c = c_abi_end_to_end(case, args, n_fl)
+        log("end_to_end_c_abi:", e2e_c)
 
     # ---- `.jf` ingestion -------------------------------------------------------
     ingest = None
@@ -709,6 +789,7 @@ def main():
                 pth = os.path.join(td, "sample_%02d.jf" % si)
                 synth.write_jf(pth, kk, cc, K)
                 paths.append(pth)
+            from km_amd import dist as kd
             kd.sample_matrix(paths[:1], files, os.path.join(td, "warm"))
             t_s = time.perf_counter()
             outs = kd.sample_matrix(paths, files, os.path.join(td, "out"))
@@ -720,32 +801,14 @@ def main():
 
     # ---- probe kernels alone (rows A2 / A3) ----------------------------------------------------
     probe = None
-    if rank == 0 and d_probe is not None and not args.only_step:
-        d_out = torch.empty(n_probe, dtype=torch.int32, device=dev)
-        d_mask = torch.empty(n_probe, dtype=torch.uint8, device=dev)
-        d_c4 = torch.empty((n_probe, 4), dtype=torch.int32, device=dev)
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        for _ in range(2):
-            db.query_dev(d_probe.data_ptr(), n_probe, d_out.data_ptr(), stream)
-            db.children_dev(d_probe.data_ptr(), n_probe, 0.05, 5, d_mask.data_ptr(), d_c4.data_ptr(), True, stream)
-        reps = 10
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            db.query_dev(d_probe.data_ptr(), n_probe, d_out.data_ptr(), stream)
-        e1.record()
-        for _ in range(reps):
-            db.children_dev(d_probe.data_ptr(), n_probe, 0.05, 5, d_mask.data_ptr(), d_c4.data_ptr(), True, stream)
-        e2.record()
-        torch.cuda.synchronize()
-        q_ms, c_ms = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
+    if rank == 0 and probe_keys is not None and not args.only_step:
+        q_ms, c_ms, n_zero = kmlib.probe_bench(db, probe_keys, reps=10, ratio=0.05, n_cutoff=5)
         probe = {"n_kmers": n_probe,
                  "query": {"ms": q_ms, "G_probes_per_s": n_probe / q_ms / 1e6,
                            "achieved_GBs": n_probe * 12 / q_ms / 1e6, "frac": n_probe * 12 / q_ms / 1e6 / HBM_PEAK_GBS},
                  "get_child": {"ms": c_ms, "G_probes_per_s": 4 * n_probe / c_ms / 1e6,
                                "achieved_GBs": n_probe * 48 / c_ms / 1e6, "frac": n_probe * 48 / c_ms / 1e6 / HBM_PEAK_GBS}}
-        assert int((d_out == 0).sum().item()) == 0        # every stored k-mer is found
-        del d_out, d_mask, d_c4
+        assert n_zero == 0                                # every stored k-mer is found
 
     # ---- BASELINE config 2: latency of ONE target (FLT3-ITD, 75-nt ITD, walk depth 65) --------
     single = None
@@ -861,6 +924,7 @@ def main():
             "config4_hard": hard,
             "config5_samples": cfg5,
             "end_to_end_host_path": e2e,
+            "end_to_end_c_abi": e2e_c,
             "single_target_latency": single,
             "probe_kernels": probe,
             "d2d_copy_GBs": d2d,

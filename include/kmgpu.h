@@ -287,6 +287,16 @@ int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_words, uint
  * the pure-chain pass handed to k_graph, [2] flagged targets the epilogue of k_dfs left to k_graph, [3] 0. */
 int km_batch_debug_counts(km_batch_t* b, uint32_t* out4);
 
+/* ---- measurement helpers (bench.py at N = 1 holds no device buffers of its own) ------------- */
+int km_device_sync(int device);                                    /* hipDeviceSynchronize on `device`          */
+/* device-to-device copy of `bytes` bytes, `reps` times: read + write GB/s (the box's large-copy
+ * rate beside the 8 TB/s spec) */
+int km_device_copy_GBs(int device, uint64_t bytes, int reps, double* gbs);
+/* the two probe kernels alone (rows A2 / A3: Jellyfish.query, get_child — km/utils/Jellyfish.py:47-72)
+ * over `n` host k-mers: average launch time over `reps` launches each, and how many have count 0 */
+int km_probe_bench(kmjf_t* h, const uint64_t* kmers, uint64_t n, int reps, double ratio, int64_t n_cutoff,
+                   double* query_ms, double* children_ms, uint64_t* n_zero);
+
 /* ---- misc ---------------------------------------------------------------- */
 const char* km_strerror(int code);
 const char* km_last_error(void);   /* thread-local detail of the last failure */

@@ -1811,6 +1811,97 @@ extern "C" int km_batch_debug_stamps(km_batch_t* b, uint64_t* dst, uint64_t cap_
   return KM_OK;
 }
 
+// ---- measurement helpers for consumers that hold no device buffers of their own (bench.py at N = 1
+// runs without PyTorch in the process: the library is then served by the ROCm installation's HIP runtime,
+// as it is for a C consumer)
+extern "C" int km_device_sync(int device) {
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());
+  return KM_OK;
+}
+
+// Device-to-device copy of `bytes` bytes, `reps` times: read + write bandwidth in GB/s (the box's
+// large-copy rate beside the 8 TB/s spec).
+extern "C" int km_device_copy_GBs(int device, uint64_t bytes, int reps, double* gbs) {
+  if (!gbs || !bytes || reps < 1) return fail(KM_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  void *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, bytes) != hipSuccess) return fail(KM_E_NOMEM, "hipMalloc failed");
+  if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(KM_E_NOMEM, "hipMalloc failed"); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+  for (int i = 0; i < reps && e == hipSuccess; ++i) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (e != hipSuccess) return fail(KM_E_HIP, "copy bandwidth measurement failed: %s", hipGetErrorString(e));
+  *gbs = 2.0 * (double)reps * (double)bytes / ((double)ms * 1e-3) / 1e9;
+  return KM_OK;
+}
+
+// k_query and k_children alone over `n` k-mers given on the host: average kernel time over `reps`
+// launches each (HIP events), and how many of the k-mers have count 0.
+extern "C" int km_probe_bench(kmjf_t* h, const uint64_t* kmers, uint64_t n, int reps, double ratio, int64_t n_cutoff,
+                              double* query_ms, double* children_ms, uint64_t* n_zero) {
+  if (!h || !kmers || !n || reps < 1 || !query_ms || !children_ms) return fail(KM_E_ARG, "bad argument");
+  if (!h->d_slots) return fail(KM_E_STATE, "table not uploaded");
+  HIPCHK(hipSetDevice(h->device));
+  uint64_t* dk = nullptr;
+  uint32_t* dq = nullptr;
+  uint8_t* dm = nullptr;
+  uint32_t* dc = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  int rc = KM_OK;
+  hipError_t e = hipMalloc((void**)&dk, n * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dq, n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dm, n);
+  if (e == hipSuccess) e = hipMalloc((void**)&dc, n * 16);
+  for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
+  if (e == hipSuccess) e = hipMemcpy(dk, kmers, n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    for (int w = 0; w < 2 && rc == KM_OK; ++w) {
+      rc = kmjf_query_batch_dev(h, dk, n, dq, nullptr);
+      if (rc == KM_OK) rc = kmjf_children_batch_dev(h, dk, n, ratio, n_cutoff, 1, dm, dc, nullptr);
+    }
+    if (rc == KM_OK) e = hipDeviceSynchronize();
+    if (rc == KM_OK && e == hipSuccess) e = hipEventRecord(ev[0], nullptr);
+    for (int i = 0; i < reps && rc == KM_OK; ++i) rc = kmjf_query_batch_dev(h, dk, n, dq, nullptr);
+    if (rc == KM_OK && e == hipSuccess) e = hipEventRecord(ev[1], nullptr);
+    for (int i = 0; i < reps && rc == KM_OK; ++i) rc = kmjf_children_batch_dev(h, dk, n, ratio, n_cutoff, 1, dm, dc, nullptr);
+    if (rc == KM_OK && e == hipSuccess) e = hipEventRecord(ev[2], nullptr);
+    if (rc == KM_OK && e == hipSuccess) e = hipEventSynchronize(ev[2]);
+    float q = 0, c = 0;
+    if (rc == KM_OK && e == hipSuccess) e = hipEventElapsedTime(&q, ev[0], ev[1]);
+    if (rc == KM_OK && e == hipSuccess) e = hipEventElapsedTime(&c, ev[1], ev[2]);
+    *query_ms = q / reps;
+    *children_ms = c / reps;
+    if (rc == KM_OK && e == hipSuccess && n_zero) {
+      std::vector<uint32_t> hq(n);
+      e = hipMemcpy(hq.data(), dq, n * 4, hipMemcpyDeviceToHost);
+      uint64_t z = 0;
+      for (uint32_t v : hq) z += v == 0;
+      *n_zero = z;
+    }
+  }
+  for (int i = 0; i < 3; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+  if (dk) (void)hipFree(dk);
+  if (dq) (void)hipFree(dq);
+  if (dm) (void)hipFree(dm);
+  if (dc) (void)hipFree(dc);
+  if (rc != KM_OK) return rc;
+  if (e != hipSuccess) return fail(KM_E_HIP, "probe benchmark failed: %s", hipGetErrorString(e));
+  return KM_OK;
+}
+
 // Diagnostics: the device counters of the last run — [0] flagged targets (k_seed), [1] unflagged
 // targets k_graph_pure handed to k_graph, [2] flagged targets the epilogue of k_dfs left to k_graph.
 extern "C" int km_batch_debug_counts(km_batch_t* b, uint32_t* out4) {

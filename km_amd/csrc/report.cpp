@@ -557,7 +557,6 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
   uint64_t* row_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n + 1));
   int32_t* err = (int32_t*)malloc(sizeof(int32_t) * std::max<size_t>(1, n));
   if (!row_off || !err) { free(row_off); free(err); return KM_E_NOMEM; }
-  std::string text;
   try {
     // targets are independent: a few host threads (KM_REPORT_THREADS, default min(cores, 16))
     // pull them off a shared counter, each block of rows is kept per target and concatenated
@@ -637,27 +636,37 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
       for (std::thread& th : pool) th.join();
     }
     if (failed) { free(row_off); free(err); return KM_E_NOMEM; }
+    // one buffer: offsets first, then the blocks are copied into place by the same number of threads
+    // (a 10 000-target batch prints ~15 MB; concatenating through a std::string and copying that again
+    // cost more than producing the rows)
     size_t total = 0;
-    for (uint32_t ti = 0; ti < n; ++ti) total += block[ti].size();
-    text.reserve(total);
-    for (uint32_t ti = 0; ti < n; ++ti) {
-      row_off[ti] = text.size();
-      text += block[ti];
+    for (uint32_t ti = 0; ti < n; ++ti) { row_off[ti] = total; total += block[ti].size(); }
+    row_off[n] = total;
+    char* buf = (char*)malloc(total + 1);
+    if (!buf) { free(row_off); free(err); return KM_E_NOMEM; }
+    std::atomic<uint32_t> next_copy(0);
+    auto copy_work = [&]() {
+      for (uint32_t lo = next_copy.fetch_add(256); lo < n; lo = next_copy.fetch_add(256))
+        for (uint32_t ti = lo; ti < std::min<uint32_t>(n, lo + 256); ++ti)
+          if (!block[ti].empty()) memcpy(buf + row_off[ti], block[ti].data(), block[ti].size());
+    };
+    if (n_thr <= 1) {
+      copy_work();
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned q = 0; q < n_thr; ++q) pool.emplace_back(copy_work);
+      for (std::thread& th : pool) th.join();
     }
-    row_off[n] = text.size();
+    buf[total] = 0;
+    *text_out = buf;
+    *row_off_out = row_off;
+    *err_out = err;
+    return KM_OK;
   } catch (...) {
     free(row_off);
     free(err);
     return KM_E_NOMEM;
   }
-  char* buf = (char*)malloc(text.size() + 1);
-  if (!buf) { free(row_off); free(err); return KM_E_NOMEM; }
-  memcpy(buf, text.data(), text.size());
-  buf[text.size()] = 0;
-  *text_out = buf;
-  *row_off_out = row_off;
-  *err_out = err;
-  return KM_OK;
 }
 
 extern "C" void km_report_free(char* text, uint64_t* row_off, int32_t* err) {

@@ -277,9 +277,12 @@ def find_mutation_samples(db_paths, run_sample=None, targets=None, params=None):
     rank r opens and processes db_paths[r], db_paths[r + world], ... entirely on its own GPU
     (`run_sample(path)`; default :func:`hip_run_sample` over `targets`); there is no collective on
     this path, only the final gather of the results, in sample order, on rank 0."""
-    import torch.distributed as dist
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    if env_world()[2] > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    else:                                   # a single process never imports torch (and with it a second HIP runtime)
+        dist, rank, world = None, 0, 1
     if run_sample is None:
         if targets is None:
             raise ValueError("find_mutation_samples needs run_sample or targets")

@@ -29,6 +29,7 @@ SYMBOLS = [
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
     "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_pump", "km_batch_debug_stamps", "km_batch_debug_counts",
+    "km_device_sync", "km_device_copy_GBs", "km_probe_bench",
     "km_report_rows", "km_report_free", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
 ]
@@ -189,6 +190,9 @@ def load():
         "km_report_rows": [C.POINTER(ReportIn), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
                            C.POINTER(C.POINTER(C.c_int32))],
         "km_device_count": [C.POINTER(i32)],
+        "km_device_sync": [i32],
+        "km_device_copy_GBs": [i32, u64, i32, C.POINTER(dbl)],
+        "km_probe_bench": [vp, vp, u64, i32, dbl, i64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(u64)],
         "km_stream_create": [i32, C.POINTER(vp)],
         "km_stream_destroy": [vp],
     }
@@ -212,6 +216,25 @@ def pump(batches, streams, steps, stages):
     bs = (C.c_void_p * n)(*[b._b for b in batches])
     sts = (C.c_void_p * n)(*[C.c_void_p(s or 0) for s in streams])
     check(lib.km_batch_pump(bs, sts, n, int(steps), int(stages)))
+
+
+def device_sync(device=0):
+    check(load().km_device_sync(int(device)))
+
+
+def device_copy_GBs(device=0, nbytes=1 << 30, reps=10):
+    out = C.c_double()
+    check(load().km_device_copy_GBs(int(device), int(nbytes), int(reps), C.byref(out)))
+    return float(out.value)
+
+
+def probe_bench(db, kmers, reps=10, ratio=0.05, n_cutoff=5):
+    """(query_ms, children_ms, n_zero): k_query / k_children alone over `kmers` (numpy uint64)."""
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    q, c, z = C.c_double(), C.c_double(), C.c_uint64()
+    check(load().km_probe_bench(db._h, ptr(kmers), kmers.size, int(reps), float(ratio), int(n_cutoff),
+                                C.byref(q), C.byref(c), C.byref(z)))
+    return float(q.value), float(c.value), int(z.value)
 
 
 def stream_create(device=0):

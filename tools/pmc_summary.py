@@ -20,7 +20,9 @@ for kname, ctrs in agg.items():
         continue
     out[kname] = {c: sum(v) / len(v) for c, v in ctrs.items()}
     out[kname]["dispatches"] = len(next(iter(ctrs.values())))
-res = {"per_kernel_avg_per_dispatch": out}
+res = {"per_kernel_avg_per_dispatch": out, "round": sys.argv[3] if len(sys.argv) > 3 else None,
+       "collected_by": "tools/collect_evidence.sh: rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 20 --warmup 4 "
+                       "--no-cpu --only-step --check 0 --inflight 1 --serial (one pass per counter group)"}
 ks = next((v for k_, v in out.items() if k_.startswith("k_seed")), None)
 if ks and "TCC_EA0_RDREQ_sum" in ks:
     r128 = ks.get("TCC_EA0_RDREQ_128B_sum", 0.0)
