@@ -208,9 +208,9 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
 #define KM_DELIVER_LEAN 16
 /* Record the HIP events km_batch_timings reads (seven event records per run; off by default). */
 #define KM_RUN_TIMED 32
-/* Measurement runs: every kernel alone on the GPU, all in `stream` (by default the pass over the
- * unflagged targets, k_graph_pure, runs beside k_dfs on a second stream; with this flag it follows
- * k_dfs, inside the graph stage of km_batch_timings).  Results are the same. */
+/* Kept for callers of round 2: a batch's kernels now ALWAYS run in `stream`, in order (the pass over the
+ * unflagged targets, k_graph_pure, used to run beside k_dfs on a side stream unless this flag was given;
+ * it follows k_dfs, inside the graph stage of km_batch_timings).  The flag changes nothing. */
 #define KM_RUN_SERIAL 64
 /* Launch the kernels asynchronously on `stream` (no host synchronisation unless
  * a target overflows the fast tier, in which case the large-tier pass needs one). */

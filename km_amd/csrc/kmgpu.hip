@@ -11,6 +11,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/kmgpu.h"
@@ -66,16 +68,56 @@ extern "C" int km_device_count(int* n) {
   return KM_OK;
 }
 
+// ---- streams.  A pipelined consumer runs a few batches at a time, each on its own launch stream.  How
+// those streams fall onto the GPU's hardware queues decides how well the batches overlap.  Measured on
+// MI355X, four batches in flight (tools/pump_min.py): with the runtime's default of 4 hardware queues and
+// k_graph_pure on a per-batch side stream (round 2's arrangement) 0.30 ms per step — every side stream
+// shares a queue with ANOTHER batch's launch stream; 0.34 when launch streams themselves end up pairwise
+// on one queue; 0.21 with 8 queues and the side streams on queues of their own; 0.19 with 8 queues and no
+// side stream at all: a batch's kernels in ONE stream, every launch stream on a queue of its own.  So
+// (1) there is no side stream any more, (2) the library asks for 8 hardware queues unless the environment
+// says otherwise — when it is loaded, i.e. before the HIP runtime reads its settings — and (3) launch
+// streams come from a per-device pool created once.
+namespace {
+__attribute__((constructor)) void km_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+constexpr int POOL_STREAMS = 7;                    // + the null stream: 8 hardware queues
+struct StreamPool {
+  std::vector<hipStream_t> launch;
+  size_t next_launch = 0;
+};
+std::mutex g_pool_mu;
+std::map<int, StreamPool> g_pools;
+
+// (device already current)
+int pool_get(int device, hipStream_t* out) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  StreamPool& p = g_pools[device];
+  if (p.launch.empty())
+    for (int i = 0; i < POOL_STREAMS; ++i) { hipStream_t st = nullptr; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); p.launch.push_back(st); }
+  *out = p.launch[p.next_launch++ % p.launch.size()];
+  return KM_OK;
+}
+bool pool_owns(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& kv : g_pools)
+    for (hipStream_t x : kv.second.launch) if (x == st) return true;
+  return false;
+}
+}  // namespace
+
 extern "C" int km_stream_create(int device, void** stream) {
   if (!stream) return fail(KM_E_ARG, "null argument");
   HIPCHK(hipSetDevice(device));
   hipStream_t st = nullptr;
-  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  int rc = pool_get(device, &st);
+  if (rc != KM_OK) return rc;
   *stream = st;
   return KM_OK;
 }
+// (pool streams live as long as the process: handing one back is a no-op)
 extern "C" int km_stream_destroy(void* stream) {
-  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  if (stream && !pool_owns((hipStream_t)stream)) HIPCHK(hipStreamDestroy((hipStream_t)stream));
   return KM_OK;
 }
 
@@ -709,9 +751,6 @@ struct km_batch {
   uint64_t node_pool0 = 0;
   bool layout_moved = false;           // the large tier re-homed some targets: restore before the next run
   DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full, d_t_nruns, d_t_refmax;
-  hipStream_t side = nullptr;          // overlaps k_graph_pure with k_dfs
-  hipEvent_t ev_seed_done = nullptr, ev_pure_done = nullptr;       // eager fork / join
-  hipEvent_t ev_cap_seed = nullptr, ev_cap_pure = nullptr;         // fork / join inside a captured step
   uint32_t pure_lds = 0;
   bool timed = false;                  // the last run recorded its timing events
   hipGraph_t graph = nullptr;          // captured step (KM_RUN_HIPGRAPH)
@@ -854,12 +893,7 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   // the walk rarely adds more than a few nodes per target: the tail grows on demand
   if (rc == KM_OK) rc = ensure_out(b, default_tail_bytes(b, max_total_bases + 16ull * max_targets, 16ull * max_targets));
   if (rc == KM_OK) {
-    if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_seed_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_pure_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_cap_seed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_cap_pure, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming) != hipSuccess)
       rc = fail(KM_E_HIP, "stream/event creation failed");
   }
   if (rc == KM_OK) {
@@ -890,11 +924,6 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_n_nodes.release(); b->d_n_ref.release(); b->d_status.release(); b->d_gstatus.release();
   b->d_npaths.release(); b->d_pathbase.release(); b->d_need_full.release(); b->d_t_nruns.release(); b->d_t_refmax.release();
   b->d_loc.release(); b->d_cnt4.release(); b->d_blk_tot.release(); b->d_blk_base.release(); b->d_scan_ticket.release(); b->d_psort.release();
-  if (b->side) (void)hipStreamDestroy(b->side);
-  if (b->ev_seed_done) (void)hipEventDestroy(b->ev_seed_done);
-  if (b->ev_pure_done) (void)hipEventDestroy(b->ev_pure_done);
-  if (b->ev_cap_seed) (void)hipEventDestroy(b->ev_cap_seed);
-  if (b->ev_cap_pure) (void)hipEventDestroy(b->ev_cap_pure);
   if (b->ev_out) (void)hipEventDestroy(b->ev_out);
   b->d_probes.release(); b->d_fetches.release();
   b->d_node_kmer.release(); b->d_node_cnt.release(); b->d_counters.release();
@@ -1368,19 +1397,11 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     if (b->n_items)
       launch_seed(b->n_items, st, wa);
     if (b->timed) HIPCHK(hipEventRecord(b->ev[4], st));
-    // unflagged targets are final after k_seed: their pure-chain check runs on the side
-    // stream while k_dfs (latency-bound, few waves) walks the flagged ones
-    // KM_RUN_SERIAL: every kernel alone on the GPU, in one stream (k_graph_pure after k_dfs) — what
-    // per-kernel measurements want; the default overlaps k_graph_pure with k_dfs on the side stream
-    hipEvent_t e_fork = capturing ? b->ev_cap_seed : b->ev_seed_done;
-    hipEvent_t e_join = capturing ? b->ev_cap_pure : b->ev_pure_done;
+    // a batch's kernels run in ONE stream, in order (k_graph_pure after k_dfs): batches overlap with each
+    // other, every launch stream on a hardware queue of its own (see "streams" above).  (Round 2 ran
+    // k_graph_pure beside k_dfs on a side stream per batch; KM_RUN_SERIAL selected today's order.)
     ga.use_need_full = 1;
-    if (!serial) {
-      HIPCHK(hipEventRecord(e_fork, st));
-      HIPCHK(hipStreamWaitEvent(b->side, e_fork, 0));
-      launch_pure(b, b->side, ga);
-      HIPCHK(hipEventRecord(e_join, b->side));
-    }
+    (void)serial;
     auto launch_dfs = [&]() {
       if (wa.tab.k == 31) hipLaunchKernelGGL((k_dfs<false, 31>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
       else hipLaunchKernelGGL((k_dfs<false, 0>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
@@ -1400,8 +1421,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     launch_dfs();
     HIPCHK(hipGetLastError());
     if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
-    if (serial) launch_pure(b, st, ga);
-    else HIPCHK(hipStreamWaitEvent(st, e_join, 0));
+    launch_pure(b, st, ga);
     launch_graph(b, st, ga);
     HIPCHK(hipGetLastError());
     graph_launched = true;

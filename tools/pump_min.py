@@ -26,6 +26,8 @@ for q in range(n_fl):
     b.set_targets_packed(ascii_[q * T:(q + 1) * T].reshape(-1), offs)
     batches.append(b)
 lean = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN
+if os.environ.get("PUMP_SERIAL"):
+    lean |= kmlib.KM_RUN_SERIAL
 full = lean & ~kmlib.KM_DELIVER_LEAN
 
 
