@@ -16,6 +16,7 @@
 // printed %.3f / %.1f — except on rounding ties and near-singular fits, which are flagged.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -32,6 +33,8 @@ namespace {
 
 // set while formatting a target whose printed values depend on the last bits of the solver
 thread_local bool g_tie = false;
+thread_local double g_fit_ms = 0.0;
+thread_local long g_fit_iters = 0;
 
 typedef std::vector<int64_t> Path;
 
@@ -222,46 +225,130 @@ void jacobi_svd(std::vector<std::vector<double>>& u, int m, std::vector<double>&
 void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& counts, int64_t n_total,
                std::vector<double>* coef_out, std::vector<double>* rvaf_out) {
   const int m = (int)paths.size();
-  // contrib[i][col] = occurrences of node i on path col, stored sparsely per column
-  std::vector<std::vector<int32_t>> col((size_t)m, std::vector<int32_t>((size_t)n_total, 0));
+  const auto fit_t0 = std::chrono::steady_clock::now();
+  // contrib[i][c] = occurrences of node i on path c, one row per node
+  std::vector<int32_t> contrib((size_t)n_total * (size_t)m, 0);
   for (int c = 0; c < m; ++c)
-    for (int64_t node : *paths[(size_t)c]) col[(size_t)c][(size_t)node] += 1;
-  // minimum-norm least squares through the SVD, numpy's rcond=None cut-off
-  // (eps * max(n, m) * sigma_max) on the singular values
-  std::vector<std::vector<double>> u((size_t)m, std::vector<double>((size_t)n_total));
-  for (int c = 0; c < m; ++c)
-    for (int64_t i = 0; i < n_total; ++i) u[(size_t)c][(size_t)i] = (double)col[(size_t)c][(size_t)i];
-  std::vector<double> v, sig;
-  jacobi_svd(u, m, v, sig);
-  double smax = 0.0;
-  for (double sj : sig) smax = std::max(smax, sj);
-  const double cutoff = std::numeric_limits<double>::epsilon() * (double)std::max<int64_t>(n_total, m) * smax;
+    for (int64_t node : *paths[(size_t)c]) contrib[(size_t)node * (size_t)m + (size_t)c] += 1;
+  // The rows of contrib take few distinct values (a node lies on the reference only, on a variant path
+  // only, on both, ...): everything below works on those PATTERNS — pattern q with its row, the number of
+  // nodes N_q that have it and the sum S_q of their counts — instead of on the ~500 nodes.
+  std::vector<std::vector<int32_t>> pat;
+  std::vector<double> pat_sum, pat_n;
+  {
+    std::vector<int32_t> row((size_t)m);
+    size_t last = 0;                                    // neighbours mostly share their pattern
+    for (int64_t i = 0; i < n_total; ++i) {
+      for (int c = 0; c < m; ++c) row[(size_t)c] = contrib[(size_t)i * (size_t)m + (size_t)c];
+      size_t q = last < pat.size() && pat[last] == row ? last : 0;
+      if (!(q < pat.size() && pat[q] == row))
+        for (q = 0; q < pat.size(); ++q) if (pat[q] == row) break;
+      if (q == pat.size()) { pat.push_back(row); pat_sum.push_back(0.0); pat_n.push_back(0.0); }
+      pat_sum[q] += (double)counts[(size_t)i];
+      pat_n[q] += 1.0;
+      last = q;
+    }
+  }
+  // Minimum-norm least squares with numpy's rcond=None cut-off (eps * max(n, m) * sigma_max on the singular
+  // values).  A^T A = sum_q N_q pat_q pat_q^T and A^T b = sum_q S_q pat_q are sums of small integers times
+  // counts, the singular values of A the square roots of the eigenvalues of the m x m matrix A^T A, its
+  // eigenvectors the right singular vectors: coef = sum_j V_j (V_j . A^T b) / lambda_j over the kept j.
+  // Squaring the condition number is harmless while the paths are well separated; a fit with a small or
+  // vanishing singular value (near-identical or identical paths: a rank-deficient cluster) goes through
+  // the one-sided Jacobi SVD of A itself, as every fit did before.
   std::vector<double> coef((size_t)m, 0.0);
-  for (int j = 0; j < m; ++j) {
-    const double sj = sig[(size_t)j];
-    // a singular value near the cut-off, or a kept one that small, leaves the answer to the
-    // last bits of the solver: let the caller recompute this target with numpy
-    if (smax > 0 && sj > 1e-14 * smax && sj < 1e-6 * smax) g_tie = true;
-    if (!(sj > cutoff)) continue;
-    double proj = 0.0;                              // (sigma_j u_j) . b / sigma_j^2
-    for (int64_t i = 0; i < n_total; ++i) proj += u[(size_t)j][(size_t)i] * (double)counts[(size_t)i];
-    proj /= sj * sj;
-    for (int r = 0; r < m; ++r) coef[(size_t)r] += v[(size_t)r * m + j] * proj;
+  bool solved = false;
+  {
+    std::vector<std::vector<double>> g((size_t)m, std::vector<double>((size_t)m, 0.0));
+    std::vector<double> atb((size_t)m, 0.0);
+    for (size_t q = 0; q < pat.size(); ++q)
+      for (int r = 0; r < m; ++r) {
+        atb[(size_t)r] += (double)pat[q][(size_t)r] * pat_sum[q];
+        for (int c = 0; c < m; ++c) g[(size_t)r][(size_t)c] += pat_n[q] * (double)pat[q][(size_t)r] * (double)pat[q][(size_t)c];
+      }
+    // cyclic Jacobi on the symmetric g: g -> diag(lambda), ev columns = eigenvectors
+    std::vector<double> ev((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) ev[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      double off = 0.0, diag = 0.0;
+      for (int p2 = 0; p2 < m; ++p2) { diag += g[(size_t)p2][(size_t)p2] * g[(size_t)p2][(size_t)p2]; for (int q2 = p2 + 1; q2 < m; ++q2) off += g[(size_t)p2][(size_t)q2] * g[(size_t)p2][(size_t)q2]; }
+      if (off <= 1e-30 * diag) break;
+      for (int p2 = 0; p2 < m; ++p2)
+        for (int q2 = p2 + 1; q2 < m; ++q2) {
+          const double apq = g[(size_t)p2][(size_t)q2];
+          if (apq == 0.0) continue;
+          const double theta = (g[(size_t)q2][(size_t)q2] - g[(size_t)p2][(size_t)p2]) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(1.0 + theta * theta));
+          const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+          for (int r = 0; r < m; ++r) {                  // columns p2, q2
+            const double gp = g[(size_t)r][(size_t)p2], gq = g[(size_t)r][(size_t)q2];
+            g[(size_t)r][(size_t)p2] = c * gp - sn * gq;
+            g[(size_t)r][(size_t)q2] = sn * gp + c * gq;
+          }
+          for (int r = 0; r < m; ++r) {                  // rows p2, q2
+            const double gp = g[(size_t)p2][(size_t)r], gq = g[(size_t)q2][(size_t)r];
+            g[(size_t)p2][(size_t)r] = c * gp - sn * gq;
+            g[(size_t)q2][(size_t)r] = sn * gp + c * gq;
+          }
+          for (int r = 0; r < m; ++r) {
+            const double vp = ev[(size_t)r * m + p2], vq = ev[(size_t)r * m + q2];
+            ev[(size_t)r * m + p2] = c * vp - sn * vq;
+            ev[(size_t)r * m + q2] = sn * vp + c * vq;
+          }
+        }
+    }
+    double lmax = 0.0, lmin = std::numeric_limits<double>::infinity();
+    for (int j = 0; j < m; ++j) { lmax = std::max(lmax, g[(size_t)j][(size_t)j]); lmin = std::min(lmin, g[(size_t)j][(size_t)j]); }
+    if (lmax > 0 && lmin > 1e-9 * lmax) {                 // sigma_min > 3e-5 sigma_max: every singular value is kept
+      for (int j = 0; j < m; ++j) {
+        double proj = 0.0;
+        for (int r = 0; r < m; ++r) proj += ev[(size_t)r * m + j] * atb[(size_t)r];
+        proj /= g[(size_t)j][(size_t)j];
+        for (int r = 0; r < m; ++r) coef[(size_t)r] += ev[(size_t)r * m + j] * proj;
+      }
+      solved = true;
+    }
+  }
+  if (!solved) {
+    std::vector<std::vector<double>> u((size_t)m, std::vector<double>((size_t)n_total));
+    for (int c = 0; c < m; ++c)
+      for (int64_t i = 0; i < n_total; ++i) u[(size_t)c][(size_t)i] = (double)contrib[(size_t)i * (size_t)m + (size_t)c];
+    std::vector<double> v, sig;
+    jacobi_svd(u, m, v, sig);
+    double smax = 0.0;
+    for (double sj : sig) smax = std::max(smax, sj);
+    const double cutoff = std::numeric_limits<double>::epsilon() * (double)std::max<int64_t>(n_total, m) * smax;
+    for (int j = 0; j < m; ++j) {
+      const double sj = sig[(size_t)j];
+      // a singular value near the cut-off, or a kept one that small, leaves the answer to the
+      // last bits of the solver: let the caller recompute this target with numpy
+      if (smax > 0 && sj > 1e-14 * smax && sj < 1e-6 * smax) g_tie = true;
+      if (!(sj > cutoff)) continue;
+      double proj = 0.0;                              // (sigma_j u_j) . b / sigma_j^2
+      for (int64_t i = 0; i < n_total; ++i) proj += u[(size_t)j][(size_t)i] * (double)counts[(size_t)i];
+      proj /= sj * sj;
+      for (int r = 0; r < m; ++r) coef[(size_t)r] += v[(size_t)r * m + j] * proj;
+    }
   }
   for (double& c : coef) if (c < 0) c = 0;
-  std::vector<double> est((size_t)n_total), grad((size_t)m);
+  // Projected gradient refinement (km/utils/PathQuant.py:111-142): grad_c = 2/n * sum_i (count_i - est_i) * contrib_ic
+  // with est_i = sum_c contrib_ic * coef_c, step 0.1, until max |grad| <= 0.01, evaluated per pattern:
+  // grad_c = 2/n * sum_q pat_qc * (S_q - N_q * est_q).  The same numbers in exact arithmetic; in floating point
+  // the sums are grouped differently, which matters as little as the difference between two BLAS builds does
+  // to the reference itself (printed values near a rounding tie are flagged and recomputed with numpy: err 100).
+  const size_t n_pat = pat.size();
+  std::vector<double> grad((size_t)m), resid(n_pat);
   double step = std::numeric_limits<double>::infinity();
   while (step > 0.01) {
-    for (int64_t i = 0; i < n_total; ++i) {
+    for (size_t q = 0; q < n_pat; ++q) {
       double e = 0.0;
-      for (int c = 0; c < m; ++c) e += (double)col[(size_t)c][(size_t)i] * coef[(size_t)c];
-      est[(size_t)i] = e;
+      for (int c = 0; c < m; ++c) e += (double)pat[q][(size_t)c] * coef[(size_t)c];
+      resid[q] = pat_sum[q] - pat_n[q] * e;          // sum over the pattern's rows of (count - est)
     }
     for (int c = 0; c < m; ++c) {
-      double s = 0.0;
-      for (int64_t i = 0; i < n_total; ++i)
-        s += 2.0 * ((double)counts[(size_t)i] - est[(size_t)i]) * (double)col[(size_t)c][(size_t)i];
-      grad[(size_t)c] = s / (double)n_total;
+      double sres = 0.0;
+      for (size_t q = 0; q < n_pat; ++q) sres += 2.0 * resid[q] * (double)pat[q][(size_t)c];
+      grad[(size_t)c] = sres / (double)n_total;
     }
     for (int c = 0; c < m; ++c) coef[(size_t)c] += 0.1 * grad[(size_t)c];
     for (int c = 0; c < m; ++c) if (coef[(size_t)c] < 0) { grad[(size_t)c] = 0; coef[(size_t)c] = 0; }
@@ -271,8 +358,10 @@ void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& 
       if (grad[(size_t)c] != grad[(size_t)c]) nan = true;
       step = std::max(step, std::fabs(grad[(size_t)c]));
     }
+    ++g_fit_iters;
     if (nan) break;                                 // np.max of a NaN is NaN; NaN > 0.01 is False
   }
+  g_fit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - fit_t0).count();
   *coef_out = coef;
   double mx = -std::numeric_limits<double>::infinity(), sum = 0.0;
   for (double c : coef) { mx = std::max(mx, c); sum += c; }
@@ -560,6 +649,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
   try {
     // targets are independent: a few host threads (KM_REPORT_THREADS, default min(cores, 16))
     // pull them off a shared counter, each block of rows is kept per target and concatenated
+    const bool trace = getenv("KM_TRACE_HOST") != nullptr;
     std::vector<std::string> block(n);
     std::atomic<uint32_t> next(0);
     std::atomic<bool> failed(false);
@@ -596,6 +686,18 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
                 (int64_t)(r.extra_off[ti + 1] - r.extra_off[ti]) != t.n_nodes - t.n_ref) { err[ti] = 5; continue; }
           }
           const uint32_t p0 = r.path_off[ti], p1 = r.path_off[ti + 1];
+          if (lean && p1 == p0 + 1 && r.run_off[p0 + 1] == r.run_off[p0] + 1 && r.run_start[r.run_off[p0]] == 0 &&
+              (int64_t)r.run_len[r.run_off[p0]] == t.n_ref) {
+            // the common case by far — a bare-reference target delivered lean, its one path the single run
+            // 0 .. n_ref-1: its one row needs neither the path's nodes nor any count
+            const double nan0 = std::numeric_limits<double>::quiet_NaN();
+            const double expr0 = t.ref_max == 0 ? nan0 : -1.0;
+            const std::string ref_seq0(t.seq, (size_t)(t.n_ref + t.k - 1));
+            block[ti] = format_row(in->db_name ? in->db_name : "", t.name, "Reference\t", nan0, expr0, r.path_min_cov[p0], 0,
+                                   ref_seq0, expr0, ref_seq0, "vs_ref");
+            block[ti].push_back('\n');
+            continue;
+          }
           t.paths.resize(p1 - p0);
           t.min_cov.assign(r.path_min_cov + p0, r.path_min_cov + p1);
           bool consistent = true;
@@ -612,7 +714,13 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
           if (!consistent) { err[ti] = 5; continue; }
           if (lean && !(t.paths.size() == 1 && is_reference(t.paths[0], t.n_ref))) { err[ti] = 5; continue; }
           g_tie = false;
+          g_fit_ms = 0.0; g_fit_iters = 0;
+          const auto tt0 = std::chrono::steady_clock::now();
           err[ti] = target_rows(t, in->db_name ? in->db_name : "", &rows);
+          if (trace) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
+            if (ms > 2.0) fprintf(stderr, "[km host] report: target %u took %.1f ms (%zu paths, %lld nodes, err %d; gradient loops %.1f ms, %ld iterations)\n", ti, ms, t.paths.size(), (long long)t.n_nodes, err[ti], g_fit_ms, g_fit_iters);
+          }
           if (err[ti]) continue;
           if (g_tie) err[ti] = 100;                    // rows are still delivered
           std::string& out = block[ti];
@@ -625,6 +733,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
         failed = true;
       }
     };
+    const auto tr0 = std::chrono::steady_clock::now();
     unsigned n_thr = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     if (const char* e = getenv("KM_REPORT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (unsigned)v; }
     n_thr = std::min<unsigned>(n_thr, std::max<uint32_t>(1, n / 64));     // small batches: no threads
@@ -635,6 +744,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
       for (unsigned q = 0; q < n_thr; ++q) pool.emplace_back(work);
       for (std::thread& th : pool) th.join();
     }
+    const auto tr1 = std::chrono::steady_clock::now();
     if (failed) { free(row_off); free(err); return KM_E_NOMEM; }
     // one buffer: offsets first, then the blocks are copied into place by the same number of threads
     // (a 10 000-target batch prints ~15 MB; concatenating through a std::string and copying that again
@@ -658,6 +768,10 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
       for (std::thread& th : pool) th.join();
     }
     buf[total] = 0;
+    if (trace)
+      fprintf(stderr, "[km host] report: %u targets, %u threads, rows %.1f ms, text assembly %.1f ms, %zu bytes\n", n, n_thr,
+              std::chrono::duration<double, std::milli>(tr1 - tr0).count(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count(), total);
     *text_out = buf;
     *row_off_out = row_off;
     *err_out = err;
