@@ -1109,3 +1109,62 @@ def test_config5_synthetic_samples_match_oracle(tmp_path):
         assert got == want, f
         n_var += sum(1 for l in got if "\tvs_ref" in l and "\tReference\t" not in l)
     assert n_var >= 3
+
+
+_EPI_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from km_amd import kmer as km, lib as kmlib, synth
+case = synth.make_case(**%(spec)r)
+db = kmlib.Database.from_records(case["keys"], case["counts"], %(k)d).upload(0)
+b = kmlib.Batch(db, max_targets=len(case["targets"]), max_total_bases=case["targets"].size)
+b.set_targets([km.decode(r) for r in case["targets"]])
+b.run()
+r = b.fetch()
+np.savez(%(out)r, left=np.array(b.debug_counts()), **{k_: v for k_, v in r.items() if isinstance(v, np.ndarray)})
+"""
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_epilogue_of_k_dfs_answers_bubbles_and_changes_nothing(k, tmp_path):
+    """The epilogue of k_dfs (walk_kernel.h) answers every flagged target whose graph is the reference chain
+    plus forward and backward bubbles (substitutions, insertions, deletions, tandem duplications, several per
+    target) and leaves the rest — dead-end branches, nested shapes — to k_graph.  Same batch with the epilogue
+    on (this process) and off (KM_EPILOGUE=0 in a child process: every flagged target through k_graph, round
+    2's path): identical arrays; most flagged targets answered by the epilogue; a sample against the C oracle."""
+    import subprocess
+    import sys
+    from oracle import c_oracle
+    spec = dict(n_targets=1200, length=300, k=k, n_keys=300_000, seed=4100 + k, variant_frac=0.9,
+                variants_per_target=(1, 3), kinds=("snv", "ins", "del", "dup"), hom_frac=0.2,
+                branch_noise_frac=0.02, noise_frac=0.02, cov=(50, 1500), exact_pad=False)
+    case = synth.make_case(**spec)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], k).upload(0)
+    b = kmlib.Batch(db, max_targets=len(case["targets"]), max_total_bases=case["targets"].size)
+    b.set_targets([km.decode(r) for r in case["targets"]])
+    b.run()
+    on = b.fetch()
+    flagged, _handed, left = b.debug_counts()
+    assert flagged > 800 and left < 0.15 * flagged, (flagged, left)     # the dead-end branches are what is left
+    out = str(tmp_path / "off.npz")
+    env = dict(os.environ, KM_EPILOGUE="0")
+    subprocess.check_call([sys.executable, "-c", _EPI_CHILD % {"root": os.path.dirname(HERE), "spec": spec, "k": k, "out": out}], env=env)
+    off = np.load(out)
+    assert int(off["left"][2]) == 0                                       # (the epilogue was off there)
+    for name in ("status", "n_ref", "probes", "node_off", "node_kmer", "node_count", "path_off", "run_off", "run_start",
+                 "run_len", "path_len", "path_min_cov"):
+        assert np.array_equal(on[name], off[name]), name
+    co = c_oracle.COracle(case["keys"], case["counts"], k)
+    noff, poff = on["node_off"].astype(np.int64), on["path_off"].astype(np.int64)
+    multi = 0
+    for t in range(0, len(case["targets"]), 4):
+        want = co.analyse(case["targets"][t])
+        assert want["status"] == int(on["status"][t]) == 0
+        assert (on["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all()
+        got = [kmlib.expand_path(on, p).tolist() for p in range(poff[t], poff[t + 1])]
+        assert got == want["paths"] and on["path_min_cov"][poff[t]:poff[t + 1]].tolist() == want["min_cov"], t
+        multi += len(got) > 2
+    assert multi > 20                                                     # several bubbles per target were among them
+    b.close()
+    db.close()
