@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,7 +34,6 @@ namespace {
 
 // set while formatting a target whose printed values depend on the last bits of the solver
 thread_local bool g_tie = false;
-thread_local double g_fit_ms = 0.0;
 thread_local long g_fit_iters = 0;
 
 typedef std::vector<int64_t> Path;
@@ -49,8 +49,9 @@ struct Target {
   const uint32_t* counts;   // NULL for a bare-reference target delivered lean: only ref_max is known
   uint32_t ref_max;         // max count over the target's own k-mers (bare-reference targets)
   int64_t n_nodes;
-  std::vector<Path> paths;
-  std::vector<uint32_t> min_cov;
+  const Path* paths;        // n_paths of them, in the worker's scratch
+  size_t n_paths;
+  const uint32_t* min_cov;
 };
 
 struct Split { int64_t start, end_ref, end_var, end_ovl; };
@@ -153,8 +154,11 @@ int name_variant(const Target& t, const Path& ref, const Path& alt, int64_t offs
   std::string gone = spell(t, only_ref, false), neu = spell(t, only_var, false);
   if (!gone.empty()) {
     if (gone == neu) return 3;
+    // while gone[-(cut+1):] == neu[-(cut+1):]: cut += 1 — with gone != neu that is the length of the common suffix
+    // (once cut + 1 exceeds the shorter string the two slices differ in length)
     size_t cut = 0;
-    while (suffix(gone, cut + 1) == suffix(neu, cut + 1)) ++cut;
+    const size_t lim = std::min(gone.size(), neu.size());
+    while (cut < lim && gone[gone.size() - 1 - cut] == neu[neu.size() - 1 - cut]) ++cut;
     if (cut) {
       gone = cut >= gone.size() ? std::string() : gone.substr(0, gone.size() - cut);
       neu = cut >= neu.size() ? std::string() : neu.substr(0, neu.size() - cut);
@@ -220,33 +224,87 @@ void jacobi_svd(std::vector<std::vector<double>>& u, int m, std::vector<double>&
   }
 }
 
-// km_amd/report.py: fit_paths.  counts: float32 values of the node counts followed by -1, -1
-// (the two capping nodes).  Returns coef and rvaf (rvaf == coef when every coefficient is 0).
-void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& counts, int64_t n_total,
-               std::vector<double>* coef_out, std::vector<double>* rvaf_out) {
+// Per-thread working storage: every container below keeps its capacity from target to target, so a worker
+// allocates while it warms up and then no more (a 10 000-target batch used to make ~400 000 small allocations,
+// most of them freed by another thread than the one that made them).
+struct RowRec {
+  size_t off, len;            // the row's text in the worker's output buffer (no trailing newline in len)
+  std::string name;           // "Type\tvariant"
+  std::string mincov;         // as printed
+  std::string note;           // "vs_ref" / "cluster N n=M"
+};
+
+struct Scratch {
+  std::vector<Path> paths;
+  std::vector<uint32_t> min_cov;
+  std::vector<uint64_t> prefix;        // prefix[i] = sum of the float32 values of the counts of nodes < i
+  Path ref, cref;
+  struct Event { int64_t pos; int32_t c, d; };
+  std::vector<Event> events;
+  std::vector<int32_t> row;
+  std::vector<Path> clipped;
+  std::vector<const Path*> set;
+  std::vector<int32_t> pat;
+  std::vector<double> pat_sum, pat_n, g, atb, ev, coef, rvaf, grad, resid;
+  std::vector<RowRec> rows;
+  size_t n_rows = 0;
+  std::vector<size_t> order;
+  std::string tmp;
+  std::vector<Split> diffs;
+};
+
+// km_amd/report.py: fit_paths over the node counts as float32 values (w.prefix holds their running sums) followed
+// by -1, -1 (the two capping nodes, on no path).  Leaves coef and rvaf in the scratch (rvaf == coef when every
+// coefficient is 0).
+void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_total, const uint32_t* raw_counts) {
   const int m = (int)paths.size();
-  const auto fit_t0 = std::chrono::steady_clock::now();
-  // contrib[i][c] = occurrences of node i on path c, one row per node
-  std::vector<int32_t> contrib((size_t)n_total * (size_t)m, 0);
-  for (int c = 0; c < m; ++c)
-    for (int64_t node : *paths[(size_t)c]) contrib[(size_t)node * (size_t)m + (size_t)c] += 1;
-  // The rows of contrib take few distinct values (a node lies on the reference only, on a variant path
-  // only, on both, ...): everything below works on those PATTERNS — pattern q with its row, the number of
-  // nodes N_q that have it and the sum S_q of their counts — instead of on the ~500 nodes.
-  std::vector<std::vector<int32_t>> pat;
-  std::vector<double> pat_sum, pat_n;
+  const size_t M = (size_t)m;
+  // contrib[i][c] = occurrences of node i on path c.  The rows of that matrix take few distinct values (a node
+  // lies on the reference only, on a variant path only, on both, ...): everything below works on those PATTERNS —
+  // pattern q with its row, the number of nodes N_q that have it and the sum S_q of their counts — instead of on
+  // the ~500 nodes, and the patterns are read off the RUNS of the paths (a path is a few stretches of consecutive
+  // node indices): between two neighbouring run ends the row is constant.  Patterns are numbered in the order of
+  // their first node, as a scan over the nodes would find them; the all-zero row (nodes on none of the paths,
+  // the two capping nodes) adds exact zeros to every sum below and is left out.  S_q comes from running sums of
+  // the counts — integers, so exact in any order.
+  std::vector<int32_t>& pat = w.pat;                    // n_pat rows of m
+  std::vector<double>&pat_sum = w.pat_sum, &pat_n = w.pat_n;
+  pat.clear(); pat_sum.clear(); pat_n.clear();
+  size_t n_pat = 0;
   {
-    std::vector<int32_t> row((size_t)m);
+    std::vector<Scratch::Event>& ev = w.events;
+    ev.clear();
+    for (int c = 0; c < m; ++c) {
+      const Path& p = *paths[(size_t)c];
+      const size_t n = p.size();
+      size_t i = 0;
+      while (i < n) {
+        size_t j = i + 1;
+        while (j < n && p[j] == p[j - 1] + 1) ++j;
+        ev.push_back(Scratch::Event{p[i], c, 1});
+        ev.push_back(Scratch::Event{p[j - 1] + 1, c, -1});
+        i = j;
+      }
+    }
+    std::sort(ev.begin(), ev.end(), [](const Scratch::Event& x, const Scratch::Event& y) { return x.pos < y.pos; });
+    std::vector<int32_t>& row = w.row;
+    row.assign(M, 0);
+    int64_t active = 0, prev = 0;
     size_t last = 0;                                    // neighbours mostly share their pattern
-    for (int64_t i = 0; i < n_total; ++i) {
-      for (int c = 0; c < m; ++c) row[(size_t)c] = contrib[(size_t)i * (size_t)m + (size_t)c];
-      size_t q = last < pat.size() && pat[last] == row ? last : 0;
-      if (!(q < pat.size() && pat[q] == row))
-        for (q = 0; q < pat.size(); ++q) if (pat[q] == row) break;
-      if (q == pat.size()) { pat.push_back(row); pat_sum.push_back(0.0); pat_n.push_back(0.0); }
-      pat_sum[q] += (double)counts[(size_t)i];
-      pat_n[q] += 1.0;
-      last = q;
+    for (size_t e = 0; e < ev.size();) {
+      const int64_t pos = ev[e].pos;
+      if (active && pos > prev) {                       // nodes prev .. pos-1 have the row `row`
+        auto same = [&](size_t q) { return memcmp(pat.data() + q * M, row.data(), M * sizeof(int32_t)) == 0; };
+        size_t q = last;
+        if (!(q < n_pat && same(q)))
+          for (q = 0; q < n_pat; ++q) if (same(q)) break;
+        if (q == n_pat) { pat.insert(pat.end(), row.begin(), row.end()); pat_sum.push_back(0.0); pat_n.push_back(0.0); ++n_pat; }
+        pat_sum[q] += (double)(w.prefix[(size_t)pos] - w.prefix[(size_t)prev]);
+        pat_n[q] += (double)(pos - prev);
+        last = q;
+      }
+      for (; e < ev.size() && ev[e].pos == pos; ++e) { row[(size_t)ev[e].c] += ev[e].d; active += ev[e].d; }
+      prev = pos;
     }
   }
   // Minimum-norm least squares with numpy's rcond=None cut-off (eps * max(n, m) * sigma_max on the singular
@@ -256,78 +314,83 @@ void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& 
   // Squaring the condition number is harmless while the paths are well separated; a fit with a small or
   // vanishing singular value (near-identical or identical paths: a rank-deficient cluster) goes through
   // the one-sided Jacobi SVD of A itself, as every fit did before.
-  std::vector<double> coef((size_t)m, 0.0);
+  std::vector<double>& coef = w.coef;
+  coef.assign(M, 0.0);
   bool solved = false;
   {
-    std::vector<std::vector<double>> g((size_t)m, std::vector<double>((size_t)m, 0.0));
-    std::vector<double> atb((size_t)m, 0.0);
-    for (size_t q = 0; q < pat.size(); ++q)
-      for (int r = 0; r < m; ++r) {
-        atb[(size_t)r] += (double)pat[q][(size_t)r] * pat_sum[q];
-        for (int c = 0; c < m; ++c) g[(size_t)r][(size_t)c] += pat_n[q] * (double)pat[q][(size_t)r] * (double)pat[q][(size_t)c];
+    std::vector<double>&g = w.g, &atb = w.atb, &ev = w.ev;
+    g.assign(M * M, 0.0);
+    atb.assign(M, 0.0);
+    for (size_t q = 0; q < n_pat; ++q)
+      for (size_t r = 0; r < M; ++r) {
+        atb[r] += (double)pat[q * M + r] * pat_sum[q];
+        for (size_t c = 0; c < M; ++c) g[r * M + c] += pat_n[q] * (double)pat[q * M + r] * (double)pat[q * M + c];
       }
     // cyclic Jacobi on the symmetric g: g -> diag(lambda), ev columns = eigenvectors
-    std::vector<double> ev((size_t)m * m, 0.0);
-    for (int i = 0; i < m; ++i) ev[(size_t)i * m + i] = 1.0;
+    ev.assign(M * M, 0.0);
+    for (size_t i = 0; i < M; ++i) ev[i * M + i] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
       double off = 0.0, diag = 0.0;
-      for (int p2 = 0; p2 < m; ++p2) { diag += g[(size_t)p2][(size_t)p2] * g[(size_t)p2][(size_t)p2]; for (int q2 = p2 + 1; q2 < m; ++q2) off += g[(size_t)p2][(size_t)q2] * g[(size_t)p2][(size_t)q2]; }
+      for (size_t p2 = 0; p2 < M; ++p2) { diag += g[p2 * M + p2] * g[p2 * M + p2]; for (size_t q2 = p2 + 1; q2 < M; ++q2) off += g[p2 * M + q2] * g[p2 * M + q2]; }
       if (off <= 1e-30 * diag) break;
-      for (int p2 = 0; p2 < m; ++p2)
-        for (int q2 = p2 + 1; q2 < m; ++q2) {
-          const double apq = g[(size_t)p2][(size_t)q2];
+      for (size_t p2 = 0; p2 < M; ++p2)
+        for (size_t q2 = p2 + 1; q2 < M; ++q2) {
+          const double apq = g[p2 * M + q2];
           if (apq == 0.0) continue;
-          const double theta = (g[(size_t)q2][(size_t)q2] - g[(size_t)p2][(size_t)p2]) / (2.0 * apq);
+          const double theta = (g[q2 * M + q2] - g[p2 * M + p2]) / (2.0 * apq);
           const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(1.0 + theta * theta));
           const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-          for (int r = 0; r < m; ++r) {                  // columns p2, q2
-            const double gp = g[(size_t)r][(size_t)p2], gq = g[(size_t)r][(size_t)q2];
-            g[(size_t)r][(size_t)p2] = c * gp - sn * gq;
-            g[(size_t)r][(size_t)q2] = sn * gp + c * gq;
+          for (size_t r = 0; r < M; ++r) {                // columns p2, q2
+            const double gp = g[r * M + p2], gq = g[r * M + q2];
+            g[r * M + p2] = c * gp - sn * gq;
+            g[r * M + q2] = sn * gp + c * gq;
           }
-          for (int r = 0; r < m; ++r) {                  // rows p2, q2
-            const double gp = g[(size_t)p2][(size_t)r], gq = g[(size_t)q2][(size_t)r];
-            g[(size_t)p2][(size_t)r] = c * gp - sn * gq;
-            g[(size_t)q2][(size_t)r] = sn * gp + c * gq;
+          for (size_t r = 0; r < M; ++r) {                // rows p2, q2
+            const double gp = g[p2 * M + r], gq = g[q2 * M + r];
+            g[p2 * M + r] = c * gp - sn * gq;
+            g[q2 * M + r] = sn * gp + c * gq;
           }
-          for (int r = 0; r < m; ++r) {
-            const double vp = ev[(size_t)r * m + p2], vq = ev[(size_t)r * m + q2];
-            ev[(size_t)r * m + p2] = c * vp - sn * vq;
-            ev[(size_t)r * m + q2] = sn * vp + c * vq;
+          for (size_t r = 0; r < M; ++r) {
+            const double vp = ev[r * M + p2], vq = ev[r * M + q2];
+            ev[r * M + p2] = c * vp - sn * vq;
+            ev[r * M + q2] = sn * vp + c * vq;
           }
         }
     }
     double lmax = 0.0, lmin = std::numeric_limits<double>::infinity();
-    for (int j = 0; j < m; ++j) { lmax = std::max(lmax, g[(size_t)j][(size_t)j]); lmin = std::min(lmin, g[(size_t)j][(size_t)j]); }
+    for (size_t j = 0; j < M; ++j) { lmax = std::max(lmax, g[j * M + j]); lmin = std::min(lmin, g[j * M + j]); }
     if (lmax > 0 && lmin > 1e-9 * lmax) {                 // sigma_min > 3e-5 sigma_max: every singular value is kept
-      for (int j = 0; j < m; ++j) {
+      for (size_t j = 0; j < M; ++j) {
         double proj = 0.0;
-        for (int r = 0; r < m; ++r) proj += ev[(size_t)r * m + j] * atb[(size_t)r];
-        proj /= g[(size_t)j][(size_t)j];
-        for (int r = 0; r < m; ++r) coef[(size_t)r] += ev[(size_t)r * m + j] * proj;
+        for (size_t r = 0; r < M; ++r) proj += ev[r * M + j] * atb[r];
+        proj /= g[j * M + j];
+        for (size_t r = 0; r < M; ++r) coef[r] += ev[r * M + j] * proj;
       }
       solved = true;
     }
   }
   if (!solved) {
-    std::vector<std::vector<double>> u((size_t)m, std::vector<double>((size_t)n_total));
-    for (int c = 0; c < m; ++c)
-      for (int64_t i = 0; i < n_total; ++i) u[(size_t)c][(size_t)i] = (double)contrib[(size_t)i * (size_t)m + (size_t)c];
+    std::vector<std::vector<double>> u(M, std::vector<double>((size_t)n_total, 0.0));
+    for (size_t c = 0; c < M; ++c)
+      for (int64_t node : *paths[c]) u[c][(size_t)node] += 1.0;
+    std::vector<float> counts((size_t)n_total);
+    for (int64_t i = 0; i + 2 < n_total; ++i) counts[(size_t)i] = (float)raw_counts[i];
+    counts[(size_t)n_total - 2] = counts[(size_t)n_total - 1] = -1.0f;
     std::vector<double> v, sig;
     jacobi_svd(u, m, v, sig);
     double smax = 0.0;
     for (double sj : sig) smax = std::max(smax, sj);
     const double cutoff = std::numeric_limits<double>::epsilon() * (double)std::max<int64_t>(n_total, m) * smax;
-    for (int j = 0; j < m; ++j) {
-      const double sj = sig[(size_t)j];
+    for (size_t j = 0; j < M; ++j) {
+      const double sj = sig[j];
       // a singular value near the cut-off, or a kept one that small, leaves the answer to the
       // last bits of the solver: let the caller recompute this target with numpy
       if (smax > 0 && sj > 1e-14 * smax && sj < 1e-6 * smax) g_tie = true;
       if (!(sj > cutoff)) continue;
       double proj = 0.0;                              // (sigma_j u_j) . b / sigma_j^2
-      for (int64_t i = 0; i < n_total; ++i) proj += u[(size_t)j][(size_t)i] * (double)counts[(size_t)i];
+      for (int64_t i = 0; i < n_total; ++i) proj += u[j][(size_t)i] * (double)counts[(size_t)i];
       proj /= sj * sj;
-      for (int r = 0; r < m; ++r) coef[(size_t)r] += v[(size_t)r * m + j] * proj;
+      for (size_t r = 0; r < M; ++r) coef[r] += v[r * M + j] * proj;
     }
   }
   for (double& c : coef) if (c < 0) c = 0;
@@ -336,40 +399,38 @@ void fit_paths(const std::vector<const Path*>& paths, const std::vector<float>& 
   // grad_c = 2/n * sum_q pat_qc * (S_q - N_q * est_q).  The same numbers in exact arithmetic; in floating point
   // the sums are grouped differently, which matters as little as the difference between two BLAS builds does
   // to the reference itself (printed values near a rounding tie are flagged and recomputed with numpy: err 100).
-  const size_t n_pat = pat.size();
-  std::vector<double> grad((size_t)m), resid(n_pat);
+  std::vector<double>&grad = w.grad, &resid = w.resid;
+  grad.assign(M, 0.0);
+  resid.assign(n_pat, 0.0);
   double step = std::numeric_limits<double>::infinity();
   while (step > 0.01) {
     for (size_t q = 0; q < n_pat; ++q) {
       double e = 0.0;
-      for (int c = 0; c < m; ++c) e += (double)pat[q][(size_t)c] * coef[(size_t)c];
+      for (size_t c = 0; c < M; ++c) e += (double)pat[q * M + c] * coef[c];
       resid[q] = pat_sum[q] - pat_n[q] * e;          // sum over the pattern's rows of (count - est)
     }
-    for (int c = 0; c < m; ++c) {
+    for (size_t c = 0; c < M; ++c) {
       double sres = 0.0;
-      for (size_t q = 0; q < n_pat; ++q) sres += 2.0 * resid[q] * (double)pat[q][(size_t)c];
-      grad[(size_t)c] = sres / (double)n_total;
+      for (size_t q = 0; q < n_pat; ++q) sres += 2.0 * resid[q] * (double)pat[q * M + c];
+      grad[c] = sres / (double)n_total;
     }
-    for (int c = 0; c < m; ++c) coef[(size_t)c] += 0.1 * grad[(size_t)c];
-    for (int c = 0; c < m; ++c) if (coef[(size_t)c] < 0) { grad[(size_t)c] = 0; coef[(size_t)c] = 0; }
+    for (size_t c = 0; c < M; ++c) coef[c] += 0.1 * grad[c];
+    for (size_t c = 0; c < M; ++c) if (coef[c] < 0) { grad[c] = 0; coef[c] = 0; }
     step = 0.0;
     bool nan = false;
-    for (int c = 0; c < m; ++c) {
-      if (grad[(size_t)c] != grad[(size_t)c]) nan = true;
-      step = std::max(step, std::fabs(grad[(size_t)c]));
+    for (size_t c = 0; c < M; ++c) {
+      if (grad[c] != grad[c]) nan = true;
+      step = std::max(step, std::fabs(grad[c]));
     }
     ++g_fit_iters;
     if (nan) break;                                 // np.max of a NaN is NaN; NaN > 0.01 is False
   }
-  g_fit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - fit_t0).count();
-  *coef_out = coef;
   double mx = -std::numeric_limits<double>::infinity(), sum = 0.0;
   for (double c : coef) { mx = std::max(mx, c); sum += c; }
-  if (mx == 0) *rvaf_out = coef;
-  else {
-    rvaf_out->resize(coef.size());
-    for (size_t i = 0; i < coef.size(); ++i) (*rvaf_out)[i] = coef[i] / sum;
-  }
+  w.rvaf.resize(M);
+  if (mx == 0) w.rvaf = coef;
+  else
+    for (size_t i = 0; i < M; ++i) w.rvaf[i] = coef[i] / sum;
 }
 
 // Exact least-squares answers are ratios with small denominators (means of integer counts), so
@@ -382,98 +443,168 @@ inline void note_tie(double v, double scale) {
   if (std::fabs(f - std::floor(f) - 0.5) < 1e-6) g_tie = true;
 }
 
-std::string fmt_float(const char* spec, double v) {
-  if (v != v) return "nan";
-  note_tie(v, spec[2] == '3' ? 1000.0 : 10.0);
-  char buf[64];
-  snprintf(buf, sizeof buf, spec, v);
-  return buf;
+// "%.<decimals>f" % v for decimals 1 or 3, digit for digit what printf / Python print: the double is m * 2^e
+// exactly, so round-half-even of m * 10^decimals * 2^e is integer arithmetic (printf is correctly rounded on the
+// exact value as well).  Returns the number of characters, 0 when the value is out of the range handled here.
+inline int fixed_digits(double v, int decimals, char* buf) {
+  uint64_t bits;
+  memcpy(&bits, &v, sizeof bits);
+  const bool neg = (bits >> 63) != 0;
+  const int ex = (int)((bits >> 52) & 0x7FF);
+  uint64_t mant = bits & ((1ull << 52) - 1);
+  if (ex == 0x7FF || ex >= 1023 + 50) return 0;          // nan, inf, >= 2^50: left to snprintf
+  int e = ex - 1075;
+  if (ex == 0) e = -1074; else mant |= 1ull << 52;
+  const uint64_t scale = decimals == 3 ? 1000 : 10;
+  const uint64_t P = mant * scale;                        // < 2^63
+  uint64_t Q;
+  if (e >= 0) {
+    Q = P << e;
+  } else {
+    const int sh = -e;
+    if (sh >= 64) {
+      Q = 0;                                              // P < 2^63 <= half an ulp of the last printed digit
+    } else {
+      Q = P >> sh;
+      const uint64_t rem = P & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+      if (rem > half || (rem == half && (Q & 1))) ++Q;
+    }
+  }
+  char tmp[32];
+  int n = 0;
+  uint64_t frac = Q % scale, whole = Q / scale;
+  for (int i = 0; i < decimals; ++i) { tmp[n++] = (char)('0' + frac % 10); frac /= 10; }
+  tmp[n++] = '.';
+  do { tmp[n++] = (char)('0' + whole % 10); whole /= 10; } while (whole);
+  if (neg) tmp[n++] = '-';
+  for (int i = 0; i < n; ++i) buf[i] = tmp[n - 1 - i];
+  return n;
 }
 
-std::string format_row(const char* db, const char* query, const std::string& name, double rvaf, double expr,
-                       long long min_cov, long long off, const std::string& seq, double ref_expr,
-                       const std::string& ref_seq, const std::string& note) {
-  std::string r;
-  r.reserve(seq.size() + ref_seq.size() + 128);
-  r += db; r += '\t'; r += query; r += '\t'; r += name; r += '\t';
-  r += fmt_float("%.3f", rvaf); r += '\t'; r += fmt_float("%.1f", expr); r += '\t';
-  r += std::to_string(min_cov); r += '\t'; r += std::to_string(off); r += '\t';
-  r += seq; r += '\t'; r += fmt_float("%.1f", ref_expr); r += '\t'; r += ref_seq; r += '\t'; r += note;
-  return r;
+inline void put_float(std::string& out, const char* spec, double v) {
+  if (v != v) { out += "nan"; return; }
+  const int decimals = spec[2] == '3' ? 3 : 1;
+  note_tie(v, decimals == 3 ? 1000.0 : 10.0);
+  char buf[64];
+  int n = fixed_digits(v, decimals, buf);
+  if (n == 0) n = snprintf(buf, sizeof buf, spec, v);
+  out.append(buf, (size_t)n);
+}
+
+inline void put_int(std::string& out, long long v) {
+  char buf[24];
+  char* e = buf + sizeof buf;
+  char* p = e;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) *--p = '-';
+  out.append(p, (size_t)(e - p));
+}
+
+// the sequence a path spells, appended to `out` (spell() without the temporary)
+void put_spell(std::string& out, const Target& t, const Path& p, bool whole_first) {
+  if (p.empty()) return;
+  const size_t at = out.size();
+  const size_t head = whole_first ? (size_t)t.k : 1;
+  out.resize(at + head + p.size() - 1);
+  char* o = &out[at];
+  if (whole_first) {
+    uint64_t kmer = kmer_of(t, p[0]);
+    for (int i = t.k - 1; i >= 0; --i) { o[i] = LAST[kmer & 3]; kmer >>= 2; }
+  } else {
+    o[0] = tail_of(t, p[0]);
+  }
+  o += head;
+  const size_t n = p.size();
+  if (t.kmers) {
+    for (size_t i = 1; i < n; ++i) *o++ = LAST[t.kmers[p[i]] & 3];
+    return;
+  }
+  for (size_t i = 1; i < n;) {
+    const int64_t node = p[i];
+    if (node >= t.n_ref) { *o++ = LAST[t.extra[node - t.n_ref] & 3]; ++i; continue; }
+    size_t j = i + 1;                                       // a stretch of the target's own consecutive k-mers
+    while (j < n && p[j] == p[j - 1] + 1 && p[j] < t.n_ref) ++j;
+    const char* src = t.seq + node + t.k - 1;
+    for (size_t q = 0; q < j - i; ++q) o[q] = LAST[base_code(src[q])];
+    o += j - i;
+    i = j;
+  }
+}
+
+// One TSV row (no newline) appended to `out`; `seq` is either given or spelled from `seq_path`.
+void put_row(std::string& out, const char* db, const char* query, const std::string& name, double rvaf, double expr,
+             long long min_cov, long long off, const Target& t, const Path* seq_path, const char* seq, size_t seq_len,
+             double ref_expr, const char* ref_seq, size_t ref_len, const char* note) {
+  out += db; out += '\t'; out += query; out += '\t'; out += name; out += '\t';
+  put_float(out, "%.3f", rvaf); out += '\t'; put_float(out, "%.1f", expr); out += '\t';
+  put_int(out, min_cov); out += '\t'; put_int(out, off); out += '\t';
+  if (seq_path) put_spell(out, t, *seq_path, true);
+  else out.append(seq, seq_len);
+  out += '\t'; put_float(out, "%.1f", ref_expr); out += '\t'; out.append(ref_seq, ref_len); out += '\t'; out += note;
 }
 
 // ---- the sort key of km_amd/report.py: row_key ------------------------------------------
-struct NatTok { bool is_int; std::string s; unsigned long long v; };
-typedef std::vector<NatTok> Nat;
+// natural(text) = re.split("([0-9]+)", text) with the digit runs converted to int and the rest lower-cased;
+// two such lists compare element by element (text, int, text, ... on both sides), the shorter one first when
+// one is a prefix of the other.  Done here on the two strings directly.
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
 
-Nat natural(const std::string& text) {           // re.split("([0-9]+)", text) with ints converted
-  Nat out;
-  size_t i = 0;
+int cmp_nat(const char* a, size_t na, const char* b, size_t nb) {
+  size_t i = 0, j = 0;
   while (true) {
-    size_t j = i;
-    while (j < text.size() && !(text[j] >= '0' && text[j] <= '9')) ++j;
-    NatTok t{false, text.substr(i, j - i), 0};
-    for (char& c : t.s) c = (char)tolower((unsigned char)c);
-    out.push_back(t);
-    if (j >= text.size()) break;
-    size_t e = j;
-    while (e < text.size() && text[e] >= '0' && text[e] <= '9') ++e;
-    NatTok d{true, std::string(), strtoull(text.substr(j, e - j).c_str(), nullptr, 10)};
-    out.push_back(d);
-    i = e;
-    if (i >= text.size()) { out.push_back(NatTok{false, std::string(), 0}); break; }
-  }
-  return out;
-}
-
-int cmp_nat(const Nat& a, const Nat& b) {
-  const size_t n = std::min(a.size(), b.size());
-  for (size_t i = 0; i < n; ++i) {
-    if (a[i].is_int && b[i].is_int) {
-      if (a[i].v != b[i].v) return a[i].v < b[i].v ? -1 : 1;
-    } else {
-      const int c = a[i].s.compare(b[i].s);
-      if (c) return c < 0 ? -1 : 1;
+    size_t ie = i, je = j;
+    while (ie < na && !is_digit(a[ie])) ++ie;
+    while (je < nb && !is_digit(b[je])) ++je;
+    const size_t la = ie - i, lb = je - j, n = std::min(la, lb);
+    for (size_t q = 0; q < n; ++q) {
+      const unsigned char ca = (unsigned char)tolower((unsigned char)a[i + q]), cb = (unsigned char)tolower((unsigned char)b[j + q]);
+      if (ca != cb) return ca < cb ? -1 : 1;
     }
+    if (la != lb) return la < lb ? -1 : 1;
+    i = ie; j = je;
+    const bool ea = i >= na, eb = j >= nb;
+    if (ea || eb) return ea && eb ? 0 : (ea ? -1 : 1);      // the list that ends here is the shorter one
+    while (ie < na && is_digit(a[ie])) ++ie;
+    while (je < nb && is_digit(b[je])) ++je;
+    while (i < ie - 1 && a[i] == '0') ++i;                  // integers: compare the values
+    while (j < je - 1 && b[j] == '0') ++j;
+    if (ie - i != je - j) return ie - i < je - j ? -1 : 1;
+    const int c = memcmp(a + i, b + j, ie - i);
+    if (c) return c < 0 ? -1 : 1;
+    i = ie; j = je;                                         // a text element follows on both sides (maybe "")
   }
-  return a.size() == b.size() ? 0 : (a.size() < b.size() ? -1 : 1);
 }
 
-struct RowKey { std::vector<Nat> comps; };
-
-RowKey row_key(const std::string& row) {
-  std::vector<std::string> f;
-  size_t i = 0;
-  while (true) {
-    size_t j = row.find('\t', i);
-    if (j == std::string::npos) { f.push_back(row.substr(i)); break; }
-    f.push_back(row.substr(i, j - i));
-    i = j + 1;
-  }
-  RowKey k;
-  const std::string& info = f[11];
-  size_t p = 0;
-  while (true) {
-    size_t q = info.find(' ', p);
-    if (q == std::string::npos) { k.comps.push_back(natural(info.substr(p))); break; }
-    k.comps.push_back(natural(info.substr(p, q - p)));
-    p = q + 1;
-  }
-  k.comps.push_back(natural(f[1]));
-  k.comps.push_back(natural(f[3]));
-  k.comps.push_back(natural(f[2]));
-  k.comps.push_back(natural(f[6]));
-  return k;
-}
-
-bool key_less(const RowKey& a, const RowKey& b) {
-  const size_t n = std::min(a.comps.size(), b.comps.size());
-  for (size_t i = 0; i < n; ++i) {
-    int c = cmp_nat(a.comps[i], b.comps[i]);
+// key = [natural(w) for w in info.split(" ")] + [natural(query), natural(variant), natural(type), natural(min_cov)],
+// the first component descending.  All rows of a target share the query.
+bool row_less(const RowRec& a, const RowRec& b) {
+  struct View { const char* p; size_t n; };
+  auto comps = [](const RowRec& r, View* v) -> int {
+    int n = 0;
+    size_t p = 0;
+    while (true) {
+      const size_t q = r.note.find(' ', p);
+      if (q == std::string::npos) { if (n < 12) v[n++] = View{r.note.data() + p, r.note.size() - p}; break; }
+      if (n < 12) v[n++] = View{r.note.data() + p, q - p};
+      p = q + 1;
+    }
+    const size_t tab = r.name.find('\t');
+    v[n++] = View{"", 0};                                   // the query: equal on both sides
+    v[n++] = View{r.name.data() + tab + 1, r.name.size() - tab - 1};
+    v[n++] = View{r.name.data(), tab};
+    v[n++] = View{r.mincov.data(), r.mincov.size()};
+    return n;
+  };
+  View va[16], vb[16];
+  const int na = comps(a, va), nb = comps(b, vb);
+  const int n = std::min(na, nb);
+  for (int i = 0; i < n; ++i) {
+    int c = cmp_nat(va[i].p, va[i].n, vb[i].p, vb[i].n);
     if (i == 0) c = -c;                           // the first component sorts descending
     if (c) return c < 0;
   }
-  return a.comps.size() < b.comps.size();
+  return na < nb;
 }
 
 bool is_reference(const Path& p, int64_t n_ref) {
@@ -513,58 +644,87 @@ void cluster_groups(const std::vector<Split>& diffs, std::vector<Group>* out) {
   }
 }
 
-// km_amd/report.py: target_rows.  0 ok, else the error code of name_variant / split_paths.
-int target_rows(const Target& t, const char* db, std::vector<std::string>* rows_out) {
+inline RowRec& new_row(Scratch& w, const std::string& out) {
+  if (w.n_rows == w.rows.size()) w.rows.emplace_back();
+  RowRec& r = w.rows[w.n_rows++];
+  r.off = out.size();
+  return r;
+}
+
+// km_amd/report.py: target_rows.  Appends the target's rows (each newline-terminated, in the reference's order)
+// to `out`; 0 ok, else the error code of name_variant / split_paths (then `out` is left as it was).
+int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
   const int k = t.k;
   const int64_t n_ref = t.n_ref, n_total = t.n_nodes + 2;
+  const size_t out0 = out.size();
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  const size_t ref_len = std::min<size_t>(t.seq_len, (size_t)(n_ref + k - 1));
+  static const std::string REFERENCE = "Reference\t";
   if (!t.counts) {
     // lean delivery of a bare-reference target: its single row needs the path's min coverage and
     // whether every count is 0 (then PathQuant's rVAF aliases coef and both print nan)
-    const double nan0 = std::numeric_limits<double>::quiet_NaN();
-    const double expr0 = t.ref_max == 0 ? nan0 : -1.0;
-    const std::string ref_seq0(t.seq, std::min<size_t>(t.seq_len, (size_t)(n_ref + k - 1)));
-    rows_out->clear();
-    if (t.paths.size() != 1 || !is_reference(t.paths[0], n_ref)) return 3;
-    rows_out->push_back(format_row(db, t.name, "Reference\t", nan0, expr0, t.min_cov[0], 0, ref_seq0, expr0,
-                                   ref_seq0, "vs_ref"));
+    const double expr0 = t.ref_max == 0 ? nan : -1.0;
+    if (t.n_paths != 1 || !is_reference(t.paths[0], n_ref)) return 3;
+    put_row(out, db, t.name, REFERENCE, nan, expr0, t.min_cov[0], 0, t, nullptr, t.seq, ref_len, expr0, t.seq, ref_len, "vs_ref");
+    out.push_back('\n');
     return 0;
   }
-  std::vector<float> counts((size_t)n_total);
-  for (int64_t i = 0; i < t.n_nodes; ++i) counts[(size_t)i] = (float)t.counts[i];
-  counts[(size_t)n_total - 2] = counts[(size_t)n_total - 1] = -1.0f;
-  Path ref((size_t)n_ref);
-  for (int64_t i = 0; i < n_ref; ++i) ref[(size_t)i] = i;
-  const std::string ref_seq(t.seq, std::min<size_t>(t.seq_len, (size_t)(n_ref + k - 1)));
   uint32_t ref_max = 0;
-  for (int64_t i = 0; i < n_ref; ++i) ref_max = std::max(ref_max, t.counts[i]);
-  const double nan = std::numeric_limits<double>::quiet_NaN();
+  {
+    // the reference fits float32 counts (PathQuant.py:99): running sums of exactly those values
+    w.prefix.resize((size_t)t.n_nodes + 1);
+    uint64_t acc = 0;
+    uint64_t* pre = w.prefix.data();
+    pre[0] = 0;
+    for (int64_t i = 0; i < t.n_nodes; ++i) {
+      const uint32_t c = t.counts[i];
+      if (i < n_ref) ref_max = std::max(ref_max, c);
+      acc += c < (1u << 24) ? (uint64_t)c : (uint64_t)(float)c;
+      pre[i + 1] = acc;
+    }
+  }
+  Path& ref = w.ref;                                     // 0 .. n_ref-1: what is there from the last target stays
+  {
+    const size_t have = ref.size();
+    ref.resize((size_t)n_ref);
+    for (size_t i = have; i < (size_t)n_ref; ++i) ref[i] = (int64_t)i;
+  }
   const double ref_expr = ref_max == 0 ? nan : -1.0;
-  std::vector<std::string>& rows = *rows_out;
-  rows.clear();
-  if (t.paths.size() == 1 && is_reference(t.paths[0], n_ref)) {
-    rows.push_back(format_row(db, t.name, "Reference\t", nan, ref_expr, t.min_cov[0], 0, ref_seq, ref_expr,
-                              ref_seq, "vs_ref"));
+  if (t.n_paths == 1 && is_reference(t.paths[0], n_ref)) {
+    put_row(out, db, t.name, REFERENCE, nan, ref_expr, t.min_cov[0], 0, t, nullptr, t.seq, ref_len, ref_expr, t.seq, ref_len, "vs_ref");
+    out.push_back('\n');
     return 0;
   }
-  std::vector<double> coef, rvaf;
-  for (size_t pi = 0; pi < t.paths.size(); ++pi) {
+  w.n_rows = 0;
+  auto fail = [&](int rc) { out.resize(out0); return rc; };
+  auto close_row = [&](RowRec& r, const std::string& name, long long mc, const char* note) {
+    r.len = out.size() - r.off;
+    r.name = name;
+    r.mincov.clear(); put_int(r.mincov, mc);
+    r.note = note;
+  };
+  std::string name;
+  for (size_t pi = 0; pi < t.n_paths; ++pi) {
     const Path& p = t.paths[pi];
     if (is_reference(p, n_ref)) {
-      rows.push_back(format_row(db, t.name, "Reference\t", nan, ref_expr, t.min_cov[pi], 0, ref_seq, ref_expr,
-                                ref_seq, "vs_ref"));
+      RowRec& r = new_row(w, out);
+      put_row(out, db, t.name, REFERENCE, nan, ref_expr, t.min_cov[pi], 0, t, nullptr, t.seq, ref_len, ref_expr, t.seq, ref_len, "vs_ref");
+      close_row(r, REFERENCE, t.min_cov[pi], "vs_ref");
       continue;
     }
-    fit_paths({&p, &ref}, counts, n_total, &coef, &rvaf);
-    std::string name;
-    int rc = name_variant(t, ref, p, 0, &name);
-    if (rc) return rc;
-    rows.push_back(format_row(db, t.name, name, rvaf[0], coef[0], t.min_cov[pi], 0, spell(t, p, true), coef[1],
-                              ref_seq, "vs_ref"));
+    w.set.clear(); w.set.push_back(&p); w.set.push_back(&ref);
+    fit_paths(w, w.set, n_total, t.counts);
+    const int rc = name_variant(t, ref, p, 0, &name);
+    if (rc) return fail(rc);
+    RowRec& r = new_row(w, out);
+    put_row(out, db, t.name, name, w.rvaf[0], w.coef[0], t.min_cov[pi], 0, t, &p, nullptr, 0, w.coef[1], t.seq, ref_len, "vs_ref");
+    close_row(r, name, t.min_cov[pi], "vs_ref");
   }
-  if (!t.paths.empty()) {
-    std::vector<Split> diffs(t.paths.size());
-    for (size_t pi = 0; pi < t.paths.size(); ++pi)
-      if (!split_paths(ref, t.paths[pi], k, &diffs[pi])) return 1;
+  if (t.n_paths) {
+    std::vector<Split>& diffs = w.diffs;
+    diffs.resize(t.n_paths);
+    for (size_t pi = 0; pi < t.n_paths; ++pi)
+      if (!split_paths(ref, t.paths[pi], k, &diffs[pi])) return fail(1);
     std::vector<Group> groups;
     cluster_groups(diffs, &groups);
     int num = 0;
@@ -575,41 +735,95 @@ int target_rows(const Target& t, const char* db, std::vector<std::string>* rows_
       for (int v : g.members)
         size = std::max<int64_t>(size, std::llabs(diffs[(size_t)v].end_var - diffs[(size_t)v].end_ref + 1));
       const int64_t off = std::max<int64_t>(0, g.lo - size);
-      Path cref;
+      Path& cref = w.cref;
       slice(ref, off, g.hi, &cref);
-      std::vector<Path> clipped(g.members.size());
-      for (size_t q = 0; q < g.members.size(); ++q) {
+      if (w.clipped.size() < g.members.size()) w.clipped.resize(g.members.size());
+      const size_t n_clip = g.members.size();
+      for (size_t q = 0; q < n_clip; ++q) {
         const int v = g.members[q];
-        slice(t.paths[(size_t)v], off, diffs[(size_t)v].end_var + g.hi - diffs[(size_t)v].end_ref, &clipped[q]);
+        slice(t.paths[(size_t)v], off, diffs[(size_t)v].end_var + g.hi - diffs[(size_t)v].end_ref, &w.clipped[q]);
       }
-      std::vector<const Path*> set;
-      set.push_back(&cref);
-      for (const Path& c : clipped) set.push_back(&c);
-      fit_paths(set, counts, n_total, &coef, &rvaf);
-      const std::string cref_seq = spell(t, cref, true);
+      w.set.clear();
+      w.set.push_back(&cref);
+      for (size_t q = 0; q < n_clip; ++q) w.set.push_back(&w.clipped[q]);
+      fit_paths(w, w.set, n_total, t.counts);
+      w.tmp.clear();
+      put_spell(w.tmp, t, cref, true);                     // the cluster's reference sequence
+      const std::string cref_seq = w.tmp;
       char note[64];
-      snprintf(note, sizeof note, "cluster %d n=%d", num, (int)clipped.size());
-      for (size_t q = 0; q < clipped.size(); ++q) {
-        const Path& p = clipped[q];
-        if (p.empty()) return 4;                         // min() of an empty sequence
+      snprintf(note, sizeof note, "cluster %d n=%d", num, (int)n_clip);
+      for (size_t q = 0; q < n_clip; ++q) {
+        const Path& p = w.clipped[q];
+        if (p.empty()) return fail(4);                     // min() of an empty sequence
         uint32_t mc = 0xFFFFFFFFu;
         for (int64_t node : p) mc = std::min(mc, t.counts[node]);
-        std::string name;
-        int rc = name_variant(t, cref, p, off, &name);
-        if (rc) return rc;
-        rows.push_back(format_row(db, t.name, name, rvaf[q + 1], coef[q + 1], mc, off, spell(t, p, true),
-                                  coef[0], cref_seq, note));
+        const int rc = name_variant(t, cref, p, off, &name);
+        if (rc) return fail(rc);
+        RowRec& r = new_row(w, out);
+        put_row(out, db, t.name, name, w.rvaf[q + 1], w.coef[q + 1], mc, off, t, &p, nullptr, 0, w.coef[0],
+                cref_seq.data(), cref_seq.size(), note);
+        close_row(r, name, mc, note);
       }
     }
   }
-  std::vector<RowKey> keys(rows.size());
-  std::vector<size_t> order(rows.size());
-  for (size_t i = 0; i < rows.size(); ++i) { keys[i] = row_key(rows[i]); order[i] = i; }
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key_less(keys[a], keys[b]); });
-  std::vector<std::string> sorted(rows.size());
-  for (size_t i = 0; i < rows.size(); ++i) sorted[i].swap(rows[order[i]]);
-  rows.swap(sorted);
+  // the reference's row order; rows were appended in the order they were made
+  const size_t nr = w.n_rows;
+  w.order.resize(nr);
+  for (size_t i = 0; i < nr; ++i) w.order[i] = i;
+  std::stable_sort(w.order.begin(), w.order.end(), [&](size_t a, size_t b) { return row_less(w.rows[a], w.rows[b]); });
+  w.tmp.clear();
+  for (size_t i = 0; i < nr; ++i) {
+    const RowRec& r = w.rows[w.order[i]];
+    w.tmp.append(out, r.off, r.len);
+    w.tmp.push_back('\n');                                // every row is terminated: blocks concatenate into the TSV
+  }
+  out.resize(out0);
+  out += w.tmp;
   return 0;
+}
+
+// A freed text buffer is kept for the next call (two at most): a 10 000-target batch prints ~15 MB, and a fresh
+// allocation of that size is a fresh mapping whose every page faults on first touch, on every call.
+struct TextCache {
+  std::mutex mu;
+  char* buf[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  ~TextCache() { free(buf[0]); free(buf[1]); }
+};
+TextCache g_text_cache;
+constexpr size_t TEXT_HEADER = 16;       // the capacity sits in front of the text handed out
+
+char* text_alloc(size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_text_cache.mu);
+    for (int i = 0; i < 2; ++i)
+      if (g_text_cache.buf[i] && g_text_cache.cap[i] >= bytes) {
+        char* p = g_text_cache.buf[i];
+        g_text_cache.buf[i] = nullptr;
+        return p + TEXT_HEADER;
+      }
+  }
+  const size_t cap = bytes + bytes / 8 + 4096;
+  char* p = (char*)malloc(cap + TEXT_HEADER);
+  if (!p) return nullptr;
+  memcpy(p, &cap, sizeof cap);
+  return p + TEXT_HEADER;
+}
+
+void text_free(char* text) {
+  if (!text) return;
+  char* p = text - TEXT_HEADER;
+  size_t cap;
+  memcpy(&cap, p, sizeof cap);
+  {
+    std::lock_guard<std::mutex> lk(g_text_cache.mu);
+    for (int i = 0; i < 2; ++i)
+      if (!g_text_cache.buf[i]) { g_text_cache.buf[i] = p; g_text_cache.cap[i] = cap; return; }
+    // both places taken: keep the larger buffers
+    const int small = g_text_cache.cap[0] <= g_text_cache.cap[1] ? 0 : 1;
+    if (g_text_cache.cap[small] < cap) { std::swap(g_text_cache.buf[small], p); g_text_cache.cap[small] = cap; }
+  }
+  free(p);
 }
 
 }  // namespace
@@ -647,132 +861,154 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
   int32_t* err = (int32_t*)malloc(sizeof(int32_t) * std::max<size_t>(1, n));
   if (!row_off || !err) { free(row_off); free(err); return KM_E_NOMEM; }
   try {
-    // targets are independent: a few host threads (KM_REPORT_THREADS, default min(cores, 16))
-    // pull them off a shared counter, each block of rows is kept per target and concatenated
+    // Targets are independent.  A team of host threads (KM_REPORT_THREADS, default min(cores, 16)) pulls CHUNKS of
+    // consecutive targets off a shared counter; a worker appends the rows of its chunks to ONE buffer of its own
+    // and notes, per target, how many bytes it wrote (row_off[t + 1] for now).  When every chunk is done the
+    // first worker turns the lengths into offsets and takes the text buffer, then the same team copies the
+    // chunks into place.  One team, no per-target strings.
     const bool trace = getenv("KM_TRACE_HOST") != nullptr;
-    std::vector<std::string> block(n);
-    std::atomic<uint32_t> next(0);
+    constexpr uint32_t CHUNK = 32;
+    const uint32_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    struct ChunkRec { uint32_t worker; size_t at; };
+    std::vector<ChunkRec> chunk(n_chunks);
+    unsigned n_thr = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("KM_REPORT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (unsigned)v; }
+    n_thr = std::min<unsigned>(n_thr, std::max<uint32_t>(1, n / 64));     // small batches: no threads
+    std::vector<std::string> wbuf(n_thr);
+    std::atomic<uint32_t> next(0), next_copy(0), arrived(0);
     std::atomic<bool> failed(false);
-    auto work = [&]() {
-      std::vector<std::string> rows;
+    std::atomic<int> phase(0);            // 1: offsets and the text buffer are ready, -1: allocation failed
+    char* text = nullptr;
+    const char* db = in->db_name ? in->db_name : "";
+    const auto tr0 = std::chrono::steady_clock::now();
+    std::chrono::steady_clock::time_point tr1 = tr0;
+    auto work = [&](unsigned me) {
       try {
-        for (uint32_t ti = next.fetch_add(1); ti < n; ti = next.fetch_add(1)) {
-          err[ti] = 0;
-          if (r.status[ti] != KM_T_OK) continue;
-          Target t;
-          t.name = in->names[ti] ? in->names[ti] : "";
-          t.seq = (const char*)in->bases + in->base_off[ti];
-          t.seq_len = (size_t)(in->base_off[ti + 1] - in->base_off[ti]);
-          t.k = in->k;
-          t.n_ref = r.n_ref[ti];
-          t.kmers = r.node_kmer ? r.node_kmer + r.node_off[ti] : nullptr;
-          t.extra = r.node_kmer ? nullptr : r.extra_kmer + r.extra_off[ti];
-          t.counts = r.node_count + r.node_off[ti];
-          // ---- this target's slice of the view must hang together before any of it is used
-          if (r.node_off[ti + 1] < r.node_off[ti] || r.path_off[ti + 1] < r.path_off[ti] ||
-              in->base_off[ti + 1] < in->base_off[ti]) { err[ti] = 5; continue; }
-          t.n_nodes = (int64_t)(r.node_off[ti + 1] - r.node_off[ti]);
-          t.ref_max = 0;
-          const bool lean = t.n_nodes == 0 && t.n_ref > 0;
-          if (lean) {
-            if (!r.ref_max_cov || r.ref_max_cov[ti] == 0xFFFFFFFFu) { err[ti] = 5; continue; }   // counts missing
-            t.counts = nullptr;                      // bare-reference target, delivered lean
-            t.ref_max = r.ref_max_cov[ti];
-            t.n_nodes = t.n_ref;
-          }
-          if (t.n_nodes < t.n_ref || (int64_t)t.seq_len < t.n_ref + t.k - 1) { err[ti] = 5; continue; }
-          if (!r.node_kmer) {
-            if (r.extra_off[ti + 1] < r.extra_off[ti] ||
-                (int64_t)(r.extra_off[ti + 1] - r.extra_off[ti]) != t.n_nodes - t.n_ref) { err[ti] = 5; continue; }
-          }
-          const uint32_t p0 = r.path_off[ti], p1 = r.path_off[ti + 1];
-          if (lean && p1 == p0 + 1 && r.run_off[p0 + 1] == r.run_off[p0] + 1 && r.run_start[r.run_off[p0]] == 0 &&
-              (int64_t)r.run_len[r.run_off[p0]] == t.n_ref) {
-            // the common case by far — a bare-reference target delivered lean, its one path the single run
-            // 0 .. n_ref-1: its one row needs neither the path's nodes nor any count
-            const double nan0 = std::numeric_limits<double>::quiet_NaN();
-            const double expr0 = t.ref_max == 0 ? nan0 : -1.0;
-            const std::string ref_seq0(t.seq, (size_t)(t.n_ref + t.k - 1));
-            block[ti] = format_row(in->db_name ? in->db_name : "", t.name, "Reference\t", nan0, expr0, r.path_min_cov[p0], 0,
-                                   ref_seq0, expr0, ref_seq0, "vs_ref");
-            block[ti].push_back('\n');
-            continue;
-          }
-          t.paths.resize(p1 - p0);
-          t.min_cov.assign(r.path_min_cov + p0, r.path_min_cov + p1);
-          bool consistent = true;
-          for (uint32_t p = p0; p < p1 && consistent; ++p) {
-            Path& path = t.paths[p - p0];
-            path.clear();
-            if (r.run_off[p + 1] < r.run_off[p]) { consistent = false; break; }
-            for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
-              // every node of a path is one of this target's nodes (fit_paths indexes by it)
-              if ((int64_t)r.run_start[q] + (int64_t)r.run_len[q] > t.n_nodes) { consistent = false; break; }
-              for (uint32_t j = 0; j < r.run_len[q]; ++j) path.push_back((int64_t)r.run_start[q] + j);
+        Scratch w;
+        std::string& out = wbuf[me];
+        out.reserve((size_t)n * 1600 / n_thr + 65536);
+        for (uint32_t c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) {
+          chunk[c] = ChunkRec{me, out.size()};
+          for (uint32_t ti = c * CHUNK; ti < std::min<uint32_t>(n, (c + 1) * CHUNK); ++ti) {
+            err[ti] = 0;
+            const size_t before = out.size();
+            auto done = [&]() { row_off[ti + 1] = out.size() - before; };
+            row_off[ti + 1] = 0;
+            if (r.status[ti] != KM_T_OK) continue;
+            Target t;
+            t.name = in->names[ti] ? in->names[ti] : "";
+            t.seq = (const char*)in->bases + in->base_off[ti];
+            t.seq_len = (size_t)(in->base_off[ti + 1] - in->base_off[ti]);
+            t.k = in->k;
+            t.n_ref = r.n_ref[ti];
+            t.kmers = r.node_kmer ? r.node_kmer + r.node_off[ti] : nullptr;
+            t.extra = r.node_kmer ? nullptr : r.extra_kmer + r.extra_off[ti];
+            t.counts = r.node_count + r.node_off[ti];
+            // ---- this target's slice of the view must hang together before any of it is used
+            if (r.node_off[ti + 1] < r.node_off[ti] || r.path_off[ti + 1] < r.path_off[ti] ||
+                in->base_off[ti + 1] < in->base_off[ti]) { err[ti] = 5; continue; }
+            t.n_nodes = (int64_t)(r.node_off[ti + 1] - r.node_off[ti]);
+            t.ref_max = 0;
+            const bool lean = t.n_nodes == 0 && t.n_ref > 0;
+            if (lean) {
+              if (!r.ref_max_cov || r.ref_max_cov[ti] == 0xFFFFFFFFu) { err[ti] = 5; continue; }   // counts missing
+              t.counts = nullptr;                      // bare-reference target, delivered lean
+              t.ref_max = r.ref_max_cov[ti];
+              t.n_nodes = t.n_ref;
             }
-          }
-          if (!consistent) { err[ti] = 5; continue; }
-          if (lean && !(t.paths.size() == 1 && is_reference(t.paths[0], t.n_ref))) { err[ti] = 5; continue; }
-          g_tie = false;
-          g_fit_ms = 0.0; g_fit_iters = 0;
-          const auto tt0 = std::chrono::steady_clock::now();
-          err[ti] = target_rows(t, in->db_name ? in->db_name : "", &rows);
-          if (trace) {
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
-            if (ms > 2.0) fprintf(stderr, "[km host] report: target %u took %.1f ms (%zu paths, %lld nodes, err %d; gradient loops %.1f ms, %ld iterations)\n", ti, ms, t.paths.size(), (long long)t.n_nodes, err[ti], g_fit_ms, g_fit_iters);
-          }
-          if (err[ti]) continue;
-          if (g_tie) err[ti] = 100;                    // rows are still delivered
-          std::string& out = block[ti];
-          for (size_t i = 0; i < rows.size(); ++i) {
-            out += rows[i];
-            out.push_back('\n');                     // every row is terminated: blocks concatenate into the TSV
+            if (t.n_nodes < t.n_ref || (int64_t)t.seq_len < t.n_ref + t.k - 1) { err[ti] = 5; continue; }
+            if (!r.node_kmer) {
+              if (r.extra_off[ti + 1] < r.extra_off[ti] ||
+                  (int64_t)(r.extra_off[ti + 1] - r.extra_off[ti]) != t.n_nodes - t.n_ref) { err[ti] = 5; continue; }
+            }
+            const uint32_t p0 = r.path_off[ti], p1 = r.path_off[ti + 1];
+            if (lean && p1 == p0 + 1 && r.run_off[p0 + 1] == r.run_off[p0] + 1 && r.run_start[r.run_off[p0]] == 0 &&
+                (int64_t)r.run_len[r.run_off[p0]] == t.n_ref) {
+              // the common case by far — a bare-reference target delivered lean, its one path the single run
+              // 0 .. n_ref-1: its one row needs neither the path's nodes nor any count
+              static const std::string REFERENCE = "Reference\t";
+              const double nan0 = std::numeric_limits<double>::quiet_NaN();
+              const double expr0 = t.ref_max == 0 ? nan0 : -1.0;
+              const size_t len0 = (size_t)(t.n_ref + t.k - 1);
+              put_row(out, db, t.name, REFERENCE, nan0, expr0, r.path_min_cov[p0], 0, t, nullptr, t.seq, len0, expr0,
+                      t.seq, len0, "vs_ref");
+              out.push_back('\n');
+              done();
+              continue;
+            }
+            const size_t n_paths = p1 - p0;
+            if (w.paths.size() < n_paths) w.paths.resize(n_paths);
+            t.paths = w.paths.data();
+            t.n_paths = n_paths;
+            w.min_cov.assign(r.path_min_cov + p0, r.path_min_cov + p1);
+            t.min_cov = w.min_cov.data();
+            bool consistent = true;
+            for (uint32_t p = p0; p < p1 && consistent; ++p) {
+              Path& path = w.paths[p - p0];
+              path.clear();
+              if (r.run_off[p + 1] < r.run_off[p]) { consistent = false; break; }
+              for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
+                // every node of a path is one of this target's nodes (fit_paths indexes by it)
+                if ((int64_t)r.run_start[q] + (int64_t)r.run_len[q] > t.n_nodes) { consistent = false; break; }
+                const size_t at = path.size();
+                path.resize(at + r.run_len[q]);
+                for (uint32_t j = 0; j < r.run_len[q]; ++j) path[at + j] = (int64_t)r.run_start[q] + j;
+              }
+            }
+            if (!consistent) { err[ti] = 5; continue; }
+            if (lean && !(n_paths == 1 && is_reference(t.paths[0], t.n_ref))) { err[ti] = 5; continue; }
+            g_tie = false;
+            g_fit_iters = 0;
+            const auto tt0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            err[ti] = target_rows(w, t, db, out);
+            if (trace) {
+              const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
+              if (ms > 2.0) fprintf(stderr, "[km host] report: target %u took %.1f ms (%zu paths, %lld nodes, err %d; %ld gradient iterations)\n", ti, ms, n_paths, (long long)t.n_nodes, err[ti], g_fit_iters);
+            }
+            if (err[ti]) continue;
+            if (g_tie) err[ti] = 100;                    // rows are still delivered
+            done();
           }
         }
       } catch (...) {
         failed = true;
       }
-    };
-    const auto tr0 = std::chrono::steady_clock::now();
-    unsigned n_thr = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("KM_REPORT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (unsigned)v; }
-    n_thr = std::min<unsigned>(n_thr, std::max<uint32_t>(1, n / 64));     // small batches: no threads
-    if (n_thr <= 1) {
-      work();
-    } else {
-      std::vector<std::thread> pool;
-      for (unsigned q = 0; q < n_thr; ++q) pool.emplace_back(work);
-      for (std::thread& th : pool) th.join();
-    }
-    const auto tr1 = std::chrono::steady_clock::now();
-    if (failed) { free(row_off); free(err); return KM_E_NOMEM; }
-    // one buffer: offsets first, then the blocks are copied into place by the same number of threads
-    // (a 10 000-target batch prints ~15 MB; concatenating through a std::string and copying that again
-    // cost more than producing the rows)
-    size_t total = 0;
-    for (uint32_t ti = 0; ti < n; ++ti) { row_off[ti] = total; total += block[ti].size(); }
-    row_off[n] = total;
-    char* buf = (char*)malloc(total + 1);
-    if (!buf) { free(row_off); free(err); return KM_E_NOMEM; }
-    std::atomic<uint32_t> next_copy(0);
-    auto copy_work = [&]() {
-      for (uint32_t lo = next_copy.fetch_add(256); lo < n; lo = next_copy.fetch_add(256))
-        for (uint32_t ti = lo; ti < std::min<uint32_t>(n, lo + 256); ++ti)
-          if (!block[ti].empty()) memcpy(buf + row_off[ti], block[ti].data(), block[ti].size());
+      // ---- every chunk is written: the last worker to arrive lays out the text
+      if (arrived.fetch_add(1) + 1 == n_thr) {
+        tr1 = std::chrono::steady_clock::now();
+        size_t total = 0;
+        row_off[0] = 0;
+        for (uint32_t ti = 0; ti < n; ++ti) { const size_t len = row_off[ti + 1]; row_off[ti + 1] = (total += len); }
+        text = failed ? nullptr : text_alloc(total + 1);
+        if (text) text[total] = 0;
+        phase.store(text ? 1 : -1, std::memory_order_release);
+      } else {
+        int spins = 0;
+        while (phase.load(std::memory_order_acquire) == 0)
+          if (++spins > 64) std::this_thread::yield();
+      }
+      if (phase.load(std::memory_order_acquire) != 1) return;
+      for (uint32_t c = next_copy.fetch_add(1); c < n_chunks; c = next_copy.fetch_add(1)) {
+        const uint32_t t0 = c * CHUNK, t1 = std::min<uint32_t>(n, (c + 1) * CHUNK);
+        const size_t bytes = (size_t)(row_off[t1] - row_off[t0]);
+        if (bytes) memcpy(text + row_off[t0], wbuf[chunk[c].worker].data() + chunk[c].at, bytes);
+      }
     };
     if (n_thr <= 1) {
-      copy_work();
+      work(0);
     } else {
       std::vector<std::thread> pool;
-      for (unsigned q = 0; q < n_thr; ++q) pool.emplace_back(copy_work);
+      for (unsigned q = 1; q < n_thr; ++q) pool.emplace_back(work, q);
+      work(0);
       for (std::thread& th : pool) th.join();
     }
-    buf[total] = 0;
+    if (failed || !text) { free(row_off); free(err); text_free(text); return KM_E_NOMEM; }
     if (trace)
-      fprintf(stderr, "[km host] report: %u targets, %u threads, rows %.1f ms, text assembly %.1f ms, %zu bytes\n", n, n_thr,
+      fprintf(stderr, "[km host] report: %u targets, %u threads, rows %.1f ms, text assembly %.1f ms, %llu bytes\n", n, n_thr,
               std::chrono::duration<double, std::milli>(tr1 - tr0).count(),
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count(), total);
-    *text_out = buf;
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count(),
+              (unsigned long long)row_off[n]);
+    *text_out = text;
     *row_off_out = row_off;
     *err_out = err;
     return KM_OK;
@@ -784,7 +1020,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
 }
 
 extern "C" void km_report_free(char* text, uint64_t* row_off, int32_t* err) {
-  free(text);
+  text_free(text);
   free(row_off);
   free(err);
 }

@@ -315,3 +315,66 @@ def test_inconsistent_view_through_the_binding():
     bad["node_off"][-1] += 3
     with pytest.raises(kmlib.KmError):
         kmlib.report_rows(bad, names, seqs, 21, "view.jf")
+
+
+def _build_host(tmp_path, name):
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / name)
+    subprocess.check_call([gxx, "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(HERE, "host", name + ".cpp")])
+    return exe
+
+
+def test_fixed_point_printing_is_printf(tmp_path):
+    """The rows print rVAF and expression with an integer-arithmetic "%.3f" / "%.1f" (csrc/report.cpp:
+    fixed_digits): 40 M values — random bit patterns, exact rounding ties, ratios of small integers — against
+    snprintf, digit for digit."""
+    import subprocess
+    exe = _build_host(tmp_path, "fixed_digits_check")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.strip().endswith(" 0 mismatches")
+
+
+def test_natural_order_of_rows_is_pythons(tmp_path):
+    """The row order compares natural-sort keys (km_amd/report.py: _natural — re.split("([0-9]+)"), digit runs as
+    ints, the rest lower-cased).  csrc/report.cpp compares the two strings directly, without building the lists:
+    same answer as Python's list comparison on random strings of digits, letters of both cases and punctuation."""
+    import random
+    import re
+    import subprocess
+    exe = _build_host(tmp_path, "natural_check")
+
+    def natural(text):
+        return [int(x) if x.isdigit() else x.lower() for x in re.split("([0-9]+)", text)]
+
+    rng = random.Random(77)
+    alphabet = "0012789abAB:/._-= "
+    pairs = []
+    for _ in range(20000):
+        a = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 9))).replace("\n", "")
+        if rng.random() < 0.5:                      # mostly related strings: a prefix, one edit, more digits
+            b = list(a)
+            for _ in range(rng.randint(0, 2)):
+                if b and rng.random() < 0.5:
+                    b[rng.randrange(len(b))] = rng.choice(alphabet)
+                else:
+                    b.insert(rng.randint(0, len(b)), rng.choice(alphabet))
+            b = "".join(b)[:rng.randint(0, 12)]
+        else:
+            b = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 9)))
+        pairs.append((a, b))
+    pairs += [("", ""), ("7", "007"), ("a7", "a007b"), ("45:/TCTG:45", "45:/TCTG:46"), ("cluster", "vs_ref"),
+              ("n=10", "n=9"), ("0.312", "nan"), ("123456789012345678901234567890", "123456789012345678901234567891")]
+    p = subprocess.run([exe], input="".join(a + "\n" + b + "\n" for a, b in pairs), capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode == 0
+    got = [int(x) for x in p.stdout.split()]
+    assert len(got) == len(pairs)
+    for (a, b), g in zip(pairs, got):
+        ka, kb = natural(a), natural(b)
+        want = -1 if ka < kb else (1 if ka > kb else 0)
+        assert g == want, (a, b, g, want)

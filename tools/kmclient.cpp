@@ -146,7 +146,9 @@ int main(int argc, char** argv) {
     std::vector<int> state((size_t)n_fl, 0);             // 0 free, 1 running (GPU), reported -> 0
     std::vector<char*> texts;
     std::vector<size_t> text_len;
-    uint64_t rows_total = 0, flagged_err = 0, bytes_total = 0;
+    uint64_t rows_total = 0, flagged_err = 0, bytes_total = 0, bytes_seen = 0;
+    double t_slot = 0, t_set = 0, t_run = 0, t_result = 0, t_report = 0;   // where the two threads spend a step
+    long n_acc = 0;
     std::atomic<long> next_report(0);
     long total_steps = 0;
     bool done = false;
@@ -160,7 +162,9 @@ int main(int argc, char** argv) {
         const size_t q = (size_t)(i % n_fl);
         km_batch_out_t view;
         km_batch_sizes_t sz;
+        const double r0 = now_s();
         CHECK(km_batch_result(bs[q], &view, &sz));
+        const double r1 = now_s();
         km_report_in_t in;
         memset(&in, 0, sizeof in);
         in.n_targets = T; in.bases = ascii.data() + (uint64_t)(i % n_fl) * T * L; in.base_off = off.data();
@@ -169,12 +173,17 @@ int main(int argc, char** argv) {
         uint64_t* row_off = nullptr;
         int32_t* err = nullptr;
         CHECK(km_report_rows(&in, &txt, &row_off, &err));
+        t_result += r1 - r0; t_report += now_s() - r1;
         for (uint32_t t = 0; t < T; ++t) flagged_err += err[t] != 0;
-        // the text of a step stays where the library put it (a consumer would write() it out); kept until the
-        // repeat is over, hashed outside the timed region
-        texts.push_back(txt);
-        text_len.push_back((size_t)row_off[T]);
-        km_report_free(nullptr, row_off, err);
+        // a consumer would write() the text out and release it; here the text of every distinct target set (the
+        // first n_fl steps of a repeat) is kept to be hashed outside the timed region, the rest goes straight back
+        bytes_seen += row_off[T];
+        if (i - first < n_fl) {
+          texts.push_back(txt);
+          text_len.push_back((size_t)row_off[T]);
+          txt = nullptr;
+        }
+        km_report_free(txt, row_off, err);
         {
           std::lock_guard<std::mutex> lk(mu);
           state[q] = 0;
@@ -190,13 +199,17 @@ int main(int argc, char** argv) {
       std::thread rep(reporter, total_steps);
       for (int i = 0; i < n; ++i) {
         const size_t q = (size_t)((total_steps) % n_fl);
+        const double m0 = now_s();
         {
           std::unique_lock<std::mutex> lk(mu);
           cv.wait(lk, [&] { return state[q] == 0; });
         }
+        const double m1 = now_s();
         // fresh host strings every step: the set this slot would have in a catalog run
         CHECK(km_batch_set_targets(bs[q], ascii.data() + (uint64_t)q * T * L, off.data(), T));
+        const double m2 = now_s();
         CHECK(km_batch_run(bs[q], flags, streams[q]));
+        t_slot += m1 - m0; t_set += m2 - m1; t_run += now_s() - m2; ++n_acc;
         {
           std::lock_guard<std::mutex> lk(mu);
           state[q] = 1;
@@ -217,13 +230,14 @@ int main(int argc, char** argv) {
     std::vector<double> ms;
     uint64_t fnv = 0;
     for (int r = 0; r < repeats; ++r) {
+      t_slot = t_set = t_run = t_result = t_report = 0; n_acc = 0;
       const double t0 = now_s();
       run_steps(steps);
       ms.push_back((now_s() - t0) / steps * 1e3);
       rows_total = bytes_total = 0;
       fnv = 1469598103934665603ull;
       if (r + 1 == repeats)
-        for (size_t b = 0; b < texts.size(); ++b) {
+        for (size_t b = 0; b < texts.size(); ++b) {             // one pass over every distinct target set
           bytes_total += text_len[b];
           for (size_t i = 0; i < text_len[b]; ++i) { const unsigned char ch = (unsigned char)texts[b][i]; fnv = (fnv ^ ch) * 1099511628211ull; rows_total += ch == '\n'; }
         }
@@ -231,12 +245,15 @@ int main(int argc, char** argv) {
     double best = ms[0], worst = ms[0];
     for (double v : ms) { best = v < best ? v : best; worst = v > worst ? v : worst; }
     printf("{\"mode\": \"e2e\", \"targets_per_step\": %u, \"batches_in_flight\": %d, \"steps\": %d, \"repeats\": %d, "
-           "\"ms_per_step_min\": %.6f, \"ms_per_step_max\": %.6f, \"targets_per_s_best\": %.1f, \"tsv_rows\": %llu, "
-           "\"tsv_bytes\": %llu, \"tsv_fnv1a\": \"%016llx\", \"targets_with_report_flags\": %llu, \"table_upload_s\": %.3f, "
+           "\"ms_per_step_min\": %.6f, \"ms_per_step_max\": %.6f, \"targets_per_s_best\": %.1f, \"hashed_steps\": %zu, \"tsv_rows\": %llu, "
+           "\"tsv_bytes\": %llu, \"tsv_fnv1a\": \"%016llx\", \"tsv_bytes_all_steps\": %llu, \"targets_with_report_flags\": %llu, \"table_upload_s\": %.3f, "
+           "\"main_thread_ms_per_step\": {\"wait_for_free_batch\": %.3f, \"km_batch_set_targets\": %.3f, \"km_batch_run\": %.3f}, "
+           "\"report_thread_ms_per_step\": {\"km_batch_result_wait\": %.3f, \"km_report_rows\": %.3f}, "
            "\"includes\": \"km_batch_set_targets of host strings (H2D) every step, walk + path search, lean delivery (D2H), "
            "km_report_rows on a second thread, text in one buffer\"}\n",
-           T, n_fl, steps, repeats, best, worst, T / (best * 1e-3), (unsigned long long)rows_total,
-           (unsigned long long)bytes_total, (unsigned long long)fnv, (unsigned long long)flagged_err, upload_s);
+           T, n_fl, steps, repeats, best, worst, T / (best * 1e-3), texts.size(), (unsigned long long)rows_total,
+           (unsigned long long)bytes_total, (unsigned long long)fnv, (unsigned long long)bytes_seen, (unsigned long long)flagged_err, upload_s,
+           t_slot / n_acc * 1e3, t_set / n_acc * 1e3, t_run / n_acc * 1e3, t_result / n_acc * 1e3, t_report / n_acc * 1e3);
   }
   for (int q = 0; q < n_fl; ++q) {
     CHECK(km_batch_destroy(bs[(size_t)q]));
