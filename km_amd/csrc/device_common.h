@@ -543,19 +543,19 @@ __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, 
 struct SlotHit { uint64_t ntag; uint32_t info; bool hit; };
 // (nested, so that a hit leaves through one branch: a flat loop over the sets makes the compiler chain
 // an exit flag through every later set — sixteen taken branches behind a hit in the first one)
+// (no test of the set against the bucket's size: the sets a bucket does not reach hold EMPTY tags, which no
+// group has — nine scalar compares a step otherwise, and a miss, which looks at every set, is a bucket change)
 template <uint32_t I>
 __device__ inline void bucket_find_from(const BucketLanes& b, uint64_t tag, SlotHit& h) {
   if constexpr (I < BUCKET_LANES_SETS) {
-    if (64u * I < b.S) {                             // wave-uniform
-      const unsigned long long hit_ = __ballot(b.tag[I] == tag);
-      if (hit_) {
-        const uint32_t l_ = (uint32_t)__ffsll((long long)hit_) - 1;
-        h.info = lane_u32(b.info[I], l_);
-        h.ntag = lane_u64(b.ntag[I], l_);
-        h.hit = true;
-      } else {
-        bucket_find_from<I + 1>(b, tag, h);
-      }
+    const unsigned long long hit_ = __ballot(b.tag[I] == tag);
+    if (hit_) {
+      const uint32_t l_ = (uint32_t)__ffsll((long long)hit_) - 1;
+      h.info = lane_u32(b.info[I], l_);
+      h.ntag = lane_u64(b.ntag[I], l_);
+      h.hit = true;
+    } else {
+      bucket_find_from<I + 1>(b, tag, h);
     }
   }
 }

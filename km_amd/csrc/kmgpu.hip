@@ -299,9 +299,15 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   uint64_t slots_cap = 0;
   OvfSlot* ovf = nullptr;
   uint32_t** ctr_ptr = nullptr;
+  uint32_t* settle_bits = nullptr;      // one bit per bucket: on the list below
+  uint32_t* settle_list = nullptr;      // buckets holding a key outside its home pair (k_table_settle)
+  const uint32_t SETTLE_CAP = 1u << 22;
+  const uint64_t settle_words = ((uint64_t)n_buckets + 31) / 32 + 1;
   auto bail = [&](int code, const char* what, hipError_t e) {
     if (dir) (void)hipFree(dir);
     if (caps) (void)hipFree(caps);
+    if (settle_bits) (void)hipFree(settle_bits);
+    if (settle_list) (void)hipFree(settle_list);
     if (sums) (void)hipFree(sums);
     if (d_meta) (void)hipFree(d_meta);
     if (slots) (void)hipFree(slots);
@@ -311,6 +317,8 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   };
   hipError_t e = hipMalloc((void**)&dir, dir_words * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&caps, dir_words * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&settle_bits, settle_words * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&settle_list, (uint64_t)SETTLE_CAP * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&sums, (uint64_t)n_chunks * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&d_meta, 64);
   if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
@@ -332,7 +340,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
                      (uint64_t)n_buckets, unit, tv.cshift);
   const int MAX_ROUNDS = 5;             // CAP_MAX_GEN dry rounds, up to two more doublings found by the real
                                         // insert, then one final round that places every key wherever it fits
-  unsigned long long meta[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t n_slots = 0;
   uint32_t max_probe = 2;
   int rounds = 0, dry_rounds = 0;
@@ -389,17 +397,44 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
       if (e != hipSuccess) return bail(KM_E_NOMEM, "hipMalloc failed", e);
     }
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, st, slots, n_slots);
+    (void)hipMemsetAsync(settle_bits, 0, settle_words * 4, st);
+    (void)hipMemsetAsync(d_meta + 6, 0, 16, st);
     if (n)
       hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n, 256)), dim3(256), 0, st, tv, slots, d_keys,
-                         d_counts, n, caps, final_round, d_meta);
-    e = hipMemcpyAsync(meta, d_meta, 32, hipMemcpyDeviceToHost, st);
+                         d_counts, n, caps, final_round, d_meta, settle_bits, settle_list, SETTLE_CAP);
+    e = hipMemcpyAsync(meta, d_meta, 64, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return bail(KM_E_HIP, "table build failed", e);
     if (meta[1] & 0xFFFFFFFFull) return bail(KM_E_HIP, "table build overflowed", hipSuccess);
     max_probe = std::max<uint32_t>(2, (uint32_t)meta[3] + 1);
+    // ---- settle: the buckets in which the race of the insert decided who sits where are laid out again as a
+    // function of their keys alone (k_table_settle); that layout also decides which of them double once more
+    if (n && meta[6] && meta[6] <= SETTLE_CAP && !getenv("KM_TABLE_NO_SETTLE")) {
+      const uint32_t n_list = (uint32_t)meta[6];
+      const uint32_t lds = 128u << 10;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_table_settle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+      }
+      const uint32_t race_probe = max_probe;
+      const unsigned long long n_slots_total = meta[5];
+      (void)hipMemsetAsync(d_meta + 3, 0, 8, st);
+      (void)hipMemsetAsync(d_meta + 5, 0, 8, st);
+      hipLaunchKernelGGL(k_table_settle, dim3(n_list), dim3(256), lds, st, tv, slots, settle_list, n_list, lds, caps,
+                         final_round, d_meta);
+      e = hipMemcpyAsync(meta, d_meta, 64, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return bail(KM_E_HIP, "table settle pass failed", e);
+      max_probe = std::max<uint32_t>(2, (uint32_t)meta[3] + 1);
+      if (getenv("KM_BUILD_VERBOSE"))
+        fprintf(stderr, "libkmgpu: settle pass: %u buckets laid out again by their keys alone (%llu too large: measured only); "
+                "max_probe %u (the race had %u)\n", n_list, meta[5], max_probe, race_probe);
+      meta[5] = n_slots_total;
+    }
     if (getenv("KM_BUILD_VERBOSE"))
-      fprintf(stderr, "libkmgpu: build round %d: %llu slots, %llu buckets to grow, max distance %llu\n", rounds,
-              (unsigned long long)n_slots, meta[2], meta[3]);
+      fprintf(stderr, "libkmgpu: build round %d: %llu slots, %llu buckets to grow, max distance %llu; %llu buckets (%llu slots) hold a key outside its home pair\n", rounds,
+              (unsigned long long)n_slots, meta[2], meta[3], meta[6], meta[7]);
     if (final_round) break;
     if (meta[2] == 0) break;
     hipLaunchKernelGGL(k_dir_grow, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
@@ -425,6 +460,8 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     if (err & 0xFFFFFFFFull) return bail(KM_E_HIP, "side table overflowed", hipSuccess);
   }
   (void)hipFree(caps);
+  (void)hipFree(settle_bits);
+  (void)hipFree(settle_list);
   (void)hipFree(sums);
   (void)hipFree(d_meta);
   if (ctr) (void)hipFree(ctr);

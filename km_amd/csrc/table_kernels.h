@@ -267,12 +267,14 @@ __global__ void k_table_dry(TableView t, const uint64_t* keys, const uint32_t* c
 // home pair of its bucket.  A key whose home pair is taken flags its bucket in caps[]
 // (meta[2] counts flagged buckets) — the host doubles those buckets and rebuilds — unless the
 // bucket has used up its doublings (a minimizer shared by very many similar k-mers: real
-// data at high coverage) or this is the final round (final != 0): then the key probes on
-// linearly and meta[3] records the largest probe distance used.  meta[0] counts occupied
-// slots, meta[1] != 0 reports a full bucket.
+// data at high coverage) or this is the final round (final != 0): then the key moves on to its
+// second pair and probes linearly from there; such a bucket goes on the list of k_table_settle
+// (meta[6] buckets, meta[7] their slots).  meta[0] counts occupied slots, meta[1] != 0 reports a
+// full bucket, meta[3] the largest probe distance the race produced.
 __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
                                const uint32_t* counts, uint64_t n, uint32_t* caps, int final,
-                               unsigned long long* meta) {
+                               unsigned long long* meta, uint32_t* settle_bits, uint32_t* settle_list,
+                               uint32_t settle_cap) {
   unsigned long long claimed = 0;          // slots this thread occupied (summed per wave at the end:
                                            // one same-address atomic per slot would serialise the kernel)
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -294,25 +296,35 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
       const uint64_t home = idx;
       const uint32_t gen = cap_gen(caps[g.bucket]);
       const bool may_grow = !final && gen < CAP_MAX_GEN;
-      const bool may_grow2 = !final && gen < CAP_HARD_GEN;
       bool done = false;
       for (uint64_t step = 0; step < S; ++step) {
-        if (step == 2 && may_grow) break;               // the pair is taken: grow this bucket
+        if (step == 2 && may_grow) break;               // the pair is taken (three groups want it, whoever comes
+                                                        // first): grow this bucket
         if (step == 2 && S >= 4) idx = second_pair(g.tag, S, home);             // two-choice (device_common.h)
-        if (step == 4 && may_grow2) break;              // neither pair has room: one more doubling
+        // (whether a key fits NEITHER of its pairs depends on who came first: k_table_settle decides the one
+        // further doubling such a bucket may get, from the layout it makes of the bucket's keys)
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&base[idx].tag),
                                            (unsigned long long)EMPTY, (unsigned long long)g.tag);
         claimed += old == EMPTY;
         if (old == EMPTY || old == g.tag) {
           base[idx].c[s] = (uint16_t)(v >= COUNT_ESCAPE ? COUNT_ESCAPE : v);
-          if (step >= 2) atomicMax(&meta[3], (unsigned long long)step);
+          if (step >= 2) {
+            atomicMax(&meta[3], (unsigned long long)step);
+            // a key outside its home pair: where it ended up depended on who came first.  The bucket goes on
+            // the list of k_table_settle, which lays it out again as a function of its keys alone.
+            if (settle_bits && !((atomicOr(&settle_bits[g.bucket >> 5], 1u << (g.bucket & 31)) >> (g.bucket & 31)) & 1u)) {
+              const unsigned long long at = atomicAdd(&meta[6], 1ull);
+              if (at < settle_cap) settle_list[at] = g.bucket;
+              atomicAdd(&meta[7], (unsigned long long)S);
+            }
+          }
           done = true;
           break;
         }
         if (++idx == S) idx = 0;
       }
       if (!done) {
-        if (may_grow || may_grow2) {
+        if (may_grow) {
           if (!(atomicOr(&caps[g.bucket], CAP_GROW) & CAP_GROW)) atomicAdd(&meta[2], 1ull);
         } else {
           atomicExch(reinterpret_cast<unsigned int*>(&meta[1]), 1u);
@@ -322,6 +334,139 @@ __global__ void k_table_insert(TableView t, Slot* slots, const uint64_t* keys,
   }
   for (int o = 32; o > 0; o >>= 1) claimed += __shfl_xor(claimed, o);
   if ((threadIdx.x & 63) == 0 && claimed) atomicAdd(&meta[0], claimed);
+}
+
+// Settle pass.  The insert above is a race: in a bucket that has used up its doublings, which of the groups
+// competing for a pair keeps it, and where the others end up along their probe sequences, depends on which thread
+// came first — so the same records gave a table with max_probe 4 on one build and 5 on the next.  This pass lays
+// every bucket that holds a key outside its home pair out AGAIN as a function of its keys alone: one block per
+// bucket reads the occupied slots, sorts the groups by tag, clears the bucket and enters them one after the other
+// in that order — first every group into its home pair while there is room, then the others along the rest of
+// the insert's probe sequence (second pair, linear from there) — counts following their groups.  Lookups are unchanged (same sequence, no holes before a key).  meta[3] = largest probe
+// distance over all settled buckets; a bucket too large for the block's LDS is left as the race built it and only
+// measured (meta[5] counts those).
+__global__ __launch_bounds__(256) void k_table_settle(TableView t, Slot* slots, const uint32_t* list, uint32_t n_list,
+                                                      uint32_t lds_bytes, uint32_t* caps, int final,
+                                                      unsigned long long* meta) {
+  extern __shared__ __align__(16) unsigned char settle_lds[];
+  __shared__ uint32_t n_e_s, n_gather_s, maxstep_s;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t bucket = list[blockIdx.x];
+  const uint32_t lo = t.dir[bucket], hi = t.dir[bucket + 1];
+  const uint32_t S = (uint32_t)bucket_slots(lo, hi);
+  Slot* base = slots + 2ull * lo;
+  if (tid == 0) { n_e_s = 0; n_gather_s = 0; maxstep_s = 0; }
+  __syncthreads();
+  // the probe sequence of a group, from its tag alone (the tag names the (k-1)-mer and its orientation)
+  auto sequence_of = [&](uint64_t tag, uint32_t* home, uint32_t* second) {
+    const uint64_t G = tag >> 1;
+    const uint64_t P = (t.canonical && (tag & 1)) ? revcomp(G, t.k - 1) : G;
+    const Key g = make_key(t, P);
+    *home = (uint32_t)home_slot(t, g, S);
+    *second = S >= 4 ? (uint32_t)second_pair(tag, S, *home) : (*home + 2 >= S ? 0u : *home + 2);
+  };
+  uint32_t occupied = 0;
+  for (uint32_t i = tid; i < S; i += 256) occupied += base[i].tag != EMPTY;
+  if (occupied) atomicAdd(&n_e_s, occupied);
+  __syncthreads();
+  const uint32_t n_e = n_e_s;
+  uint32_t P2 = 1;
+  while (P2 < n_e) P2 <<= 1;
+  // LDS: the new layout (S slots), then per group: tag, old slot, home, second pair, new slot
+  const uint64_t need = (uint64_t)S * sizeof(Slot) + (uint64_t)P2 * (8 + 4 * 4);
+  if (S > 0xFFFFu || need > lds_bytes) {
+    // measure only: how far along its sequence does every group sit?
+    uint32_t far = 0;
+    for (uint32_t i = tid; i < S; i += 256) {
+      const uint64_t tag = base[i].tag;
+      if (tag == EMPTY) continue;
+      uint32_t idx, second;
+      sequence_of(tag, &idx, &second);
+      for (uint32_t step = 0; step < S; ++step) {
+        if (step == 2) idx = second;
+        if (idx == i) { far = max(far, step); break; }
+        if (++idx == S) idx = 0;
+      }
+    }
+    if (far >= 2) atomicMax(&maxstep_s, far);
+    __syncthreads();
+    if (tid == 0) {
+      if (maxstep_s >= 2) atomicMax(&meta[3], (unsigned long long)maxstep_s);
+      atomicAdd(&meta[5], 1ull);
+      if (!final && maxstep_s >= 4 && cap_gen(caps[bucket]) < CAP_HARD_GEN && !(atomicOr(&caps[bucket], CAP_GROW) & CAP_GROW))
+        atomicAdd(&meta[2], 1ull);
+    }
+    return;
+  }
+  Slot* A = reinterpret_cast<Slot*>(settle_lds);
+  uint64_t* tags = reinterpret_cast<uint64_t*>(settle_lds + (uint64_t)S * sizeof(Slot));
+  uint32_t* old_at = reinterpret_cast<uint32_t*>(tags + P2);
+  uint32_t* home_at = old_at + P2;
+  uint32_t* second_at = home_at + P2;
+  uint32_t* new_at = second_at + P2;
+  for (uint32_t i = tid; i < P2; i += 256) { tags[i] = EMPTY; old_at[i] = 0; }
+  __syncthreads();                                       // (n_e_s is not touched again: every wave has the same n_e)
+  for (uint32_t i = tid; i < S; i += 256) {
+    const uint64_t tag = base[i].tag;
+    A[i].tag = EMPTY;
+    A[i].c[0] = A[i].c[1] = A[i].c[2] = A[i].c[3] = 0;
+    if (tag != EMPTY) {
+      const uint32_t at = atomicAdd(&n_gather_s, 1u);
+      tags[at] = tag;
+      old_at[at] = i;
+    }
+  }
+  __syncthreads();
+  // bitonic sort of (tag, old slot) by tag — tags are distinct, the padding (EMPTY) sorts last
+  for (uint32_t kk = 2; kk <= P2; kk <<= 1)
+    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < P2; i += 256) {
+        const uint32_t x = i ^ j;
+        if (x > i) {
+          const bool up = (i & kk) == 0;
+          const uint64_t a = tags[i], b = tags[x];
+          if ((a > b) == up) {
+            tags[i] = b; tags[x] = a;
+            const uint32_t o = old_at[i]; old_at[i] = old_at[x]; old_at[x] = o;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t e = tid; e < n_e; e += 256) sequence_of(tags[e], &home_at[e], &second_at[e]);
+  __syncthreads();
+  if (tid == 0) {
+    // home pairs first, for every group (as the race does, where nobody moves on before its pair is full — entering
+    // the groups one by one to the end of their sequences lets the early ones take the home pairs of the later
+    // ones: 6 probes where the race needed 4), then whoever found its pair taken, in the same order
+    uint32_t far = 0;
+    for (uint32_t e = 0; e < n_e; ++e) {
+      const uint32_t h = home_at[e];
+      new_at[e] = 0xFFFFFFFFu;
+      if (A[h].tag == EMPTY) { A[h].tag = tags[e]; new_at[e] = h; }
+      else if (A[h + 1].tag == EMPTY) { A[h + 1].tag = tags[e]; new_at[e] = h + 1; }
+    }
+    for (uint32_t e = 0; e < n_e; ++e) {
+      if (new_at[e] != 0xFFFFFFFFu) continue;
+      uint32_t idx = second_at[e];
+      for (uint32_t step = 2; step < S; ++step) {
+        if (A[idx].tag == EMPTY) { A[idx].tag = tags[e]; new_at[e] = idx; far = max(far, step); break; }
+        if (++idx == S) idx = 0;
+      }
+    }
+    if (far >= 2) atomicMax(&meta[3], (unsigned long long)far);
+    // a group that fits neither of its pairs: the bucket gets its one further doubling (and the table another round)
+    if (!final && far >= 4 && cap_gen(caps[bucket]) < CAP_HARD_GEN && !(atomicOr(&caps[bucket], CAP_GROW) & CAP_GROW))
+      atomicAdd(&meta[2], 1ull);
+  }
+  __syncthreads();
+  for (uint32_t e = tid; e < n_e; e += 256) {
+    const Slot src = base[old_at[e]];
+    Slot& dst = A[new_at[e]];
+    dst.c[0] = src.c[0]; dst.c[1] = src.c[1]; dst.c[2] = src.c[2]; dst.c[3] = src.c[3];
+  }
+  __syncthreads();                                       // every old slot is read before the first is overwritten
+  for (uint32_t i = tid; i < S; i += 256) base[i] = A[i];
 }
 
 // Jellyfish.query for a batch (km/utils/Jellyfish.py:47-53; the loop of

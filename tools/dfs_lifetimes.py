@@ -44,5 +44,18 @@ order = np.argsort(-(t1 - base))[:8]
 for i in order:
     print("  target %5d: start %.1f, setup %.1f, walk %.1f, epilogue %.1f, end %.1f us, %d new nodes" %
           (rec[i, 2], t0[i] - base, ts[i] - t0[i], tw[i] - ts[i], t1[i] - tw[i], t1[i] - base, rec[i, 3]))
+# what a wave's walk time goes with: the nodes it discovers (chain steps) — a straight-line fit and its residue
+nodes = rec[:, 3].astype(np.float64)
+walk = tw - ts
+A = np.stack([np.ones_like(nodes), nodes], axis=1)
+coef, *_ = np.linalg.lstsq(A, walk, rcond=None)
+res = walk - A @ coef
+print("walk time ~ %.1f us + %.3f us per new node (r = %.2f); residue p50 %.1f p90 %.1f p99 %.1f max %.1f us" %
+      (coef[0], coef[1], np.corrcoef(nodes, walk)[0, 1], *np.percentile(res, [50, 90, 99, 100])))
+for lo, hi in ((0, 1), (1, 20), (20, 32), (32, 45), (45, 70), (70, 100), (100, 1000)):
+    m = (nodes >= lo) & (nodes < hi)
+    if m.any():
+        print("  %3d-%3d new nodes: %5d waves, walk p50 %.1f p90 %.1f max %.1f us, life p50 %.1f max %.1f" %
+              (lo, hi - 1, m.sum(), *np.percentile(walk[m], [50, 90, 100]), np.median(life[m]), life[m].max()))
 b.close()
 db.close()

@@ -55,6 +55,15 @@ for i in order[:8]:
           "loads (largest %4d slots), %3d non-resident lookups, %3d new nodes, %d stamps:\n      " %
           (r[18], r[17], r[25], r[17] - r[25] - sec.sum(), r[16], r[23], r[24], r[20], r[22], r[21], r[26], r[27]) +
           ", ".join("%s %d" % (nm, v) for nm, v in zip(names, sec) if v))
+mid = order[len(order) // 2 - 2:len(order) // 2 + 2]
+print("four waves around the median:")
+for i in mid:
+    r = rec[i]
+    sec = r[:16].astype(np.float64)
+    print("  target %5d: %7d ticks (setup %5d, unaccounted %5d), %3d steps of which %2d general, %d runs, %2d bucket "
+          "loads (largest %4d slots), %3d non-resident lookups, %3d new nodes, %d stamps:\n      " %
+          (r[18], r[17], r[25], r[17] - r[25] - sec.sum(), r[16], r[23], r[24], r[20], r[22], r[21], r[26], r[27]) +
+          ", ".join("%s %d" % (nm, v) for nm, v in zip(names, sec) if v))
 print("bucket loads %d, chain lookups in a bucket too large for the lanes %d, largest bucket %d slots; "
       "loads per wave p50 %d max %d" % (rec[:, 20].sum(), rec[:, 21].sum(), rec[:, 22].max(), np.median(rec[:, 20]), rec[:, 20].max()))
 print("largest-bucket histogram (per wave, bins of 32 slots):", np.bincount(np.minimum(rec[:, 22] // 32, 16).astype(np.int64)).tolist())
