@@ -275,7 +275,7 @@ def hard_workload(args, case, dev_index, stream, T, n_fl):
         bq.set_targets_packed(blob[sid * T:(sid + 1) * T].reshape(-1), offsets)
         batches.append(bq)
     stages = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
-    deliver = stages | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN
+    deliver = stages | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN | kmlib.KM_DELIVER_COUNT16
     kmlib.pump(batches, streams, max(n_fl, args.warmup), deliver)
     dts = []
     for _ in range(max(1, args.repeats)):
@@ -570,7 +570,8 @@ def main():
     deliver_full = stages | kmlib.KM_RUN_DELIVER
     # lean delivery: what `km find_mutation` needs to print its TSV (km_amd.finder.BatchFinder.rows):
     # bare-reference targets are delivered as path + min coverage + ref_max_cov, without their counts
-    deliver = deliver_full | kmlib.KM_DELIVER_LEAN
+    # ... and node counts as 16-bit values + the list of the exact counts >= 65535 (KM_DELIVER_COUNT16)
+    deliver = deliver_full | kmlib.KM_DELIVER_LEAN | kmlib.KM_DELIVER_COUNT16
 
     def pipeline(n_steps, flags, wait):
         """n_steps steps round-robin over the workspaces; before a workspace is reused (and at
@@ -617,7 +618,9 @@ def main():
 
     def delivered_bytes():
         vs = [bq.result() for bq in batches]
-        return vs, float(np.mean([sum(v[x].nbytes for x in v if isinstance(v[x], np.ndarray)) for v in vs]))
+        # (with 16-bit counts the view also carries a 32-bit copy made on the host: not delivered)
+        return vs, float(np.mean([sum(v[x].nbytes for x in v if isinstance(v[x], np.ndarray)
+                                      and not (x == "node_count" and "node_count16" in v)) for v in vs]))
 
     if args.timeline:
         dts = [timed(deliver, True) for _ in range(max(1, args.repeats))]
@@ -893,8 +896,9 @@ def main():
                             "note": "same steps without result delivery (results left in HBM)"},
             "delivered_bytes_per_step": out_bytes,
             "d2h_GBs_inside_pipeline": gb(out_bytes, ms_per_step),
-            "delivery": "lean (KM_DELIVER_LEAN): statuses, probes, paths, min coverages, walk-discovered k-mers and "
-                        "the counts of every target that has them or more than one path; a bare-reference target "
+            "delivery": "lean (KM_DELIVER_LEAN | KM_DELIVER_COUNT16): statuses, probes, paths, min coverages, "
+                        "walk-discovered k-mers and the counts of every target that has them or more than one path "
+                        "(16-bit values + the exact counts >= 65535 in a list); a bare-reference target "
                         "(one Reference row in the TSV) is delivered as path + min coverage + max count",
             "full_delivery": {"value": world * T / (dt_full / args.steps), "ms_per_step": dt_full / args.steps * 1e3,
                               "delivered_bytes_per_step": out_bytes_full,

@@ -88,6 +88,8 @@ typedef struct {
   uint32_t n_flagged;      /* targets with at least one non-trivial seed       */
   uint64_t seed_probes;    /* logical probes answered by the k_seed kernel     */
   uint64_t n_extra;        /* walk-discovered nodes over all targets (n_nodes minus the targets' own k-mers) */
+  uint32_t n_count_escapes;/* entries of count_esc_node / count_esc_value (KM_DELIVER_COUNT16), else 0            */
+  uint32_t reserved;
 } km_batch_sizes_t;
 
 /* Host-side result arrays.  km_batch_fetch() fills caller-allocated arrays (numpy; any
@@ -128,6 +130,12 @@ typedef struct {
   uint32_t* ref_max_cov;   /* [n_targets]   bare-reference targets (the only path is the target's own
                                             k-mer chain, no walk-discovered node): max count over
                                             the target's k-mers; 0xFFFFFFFF for every other target */
+  /* KM_DELIVER_COUNT16 (km_batch_result only): node_count is NULL and the counts arrive as 16-bit values,
+   * same indexing (node_off); a count >= 65535 reads 0xFFFF there and its exact value is in the escape
+   * list, sorted by node index (global index into node_count16).  Half the bytes of a delivery are counts. */
+  uint16_t* node_count16;    /* [n_nodes]                                                 */
+  uint64_t* count_esc_node;  /* [n_count_escapes] ascending                               */
+  uint32_t* count_esc_value; /* [n_count_escapes]                                         */
 } km_batch_out_t;
 
 /* ---- database: replaces Jellyfish.__init__ (km/utils/Jellyfish.py:23-45) and
@@ -206,6 +214,10 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
  * other target is delivered in full.  km_report_rows accepts both forms; km_batch_fetch always
  * returns every node (re-delivering if the last delivery was lean). */
 #define KM_DELIVER_LEAN 16
+/* With KM_RUN_DELIVER: node counts cross PCIe as 16-bit values + a short list of the exact counts >= 65535
+ * (km_batch_out_t.node_count16 / count_esc_*; at most 2048 of those per delivery, else the library quietly
+ * delivers the 32-bit form).  km_report_rows reads either form; km_batch_fetch always fills 32-bit counts. */
+#define KM_DELIVER_COUNT16 128
 /* Record the HIP events km_batch_timings reads (seven event records per run; off by default). */
 #define KM_RUN_TIMED 32
 /* Kept for callers of round 2: a batch's kernels now ALWAYS run in `stream`, in order (the pass over the

@@ -11,7 +11,9 @@
 //     status[n] n_ref[n] probes[n] ref_max_cov[n]    per target
 //     node_off[n+1] extra_off[n+1] path_off[n+1]     CSR offsets
 //   tail (sub-offsets in totals[], every array 16-byte aligned)
-//     node_count[n_nodes]     counts of every node, target k-mers first          (CSR node_off)
+//     node_count[n_nodes]     counts of every node, target k-mers first          (CSR node_off);
+//                             with KM_DELIVER_COUNT16 two bytes each, a count >= 65535 as 0xFFFF and exactly
+//                             in the escape list of region A (esc_node / esc_value, totals[OT_N_ESC] entries)
 //     extra_kmer[n_extra]     packed k-mers of the walk-discovered nodes only    (CSR extra_off)
 //                             — a target's own k-mers are not shipped: node i < n_ref is the
 //                             k-mer at base i of the target the caller already holds
@@ -44,8 +46,10 @@ enum {
                         // bit 1: the tail does not fit the delivery buffer (nothing was packed)
   OT_OFF_COUNT, OT_OFF_EXTRA, OT_OFF_PLEN, OT_OFF_PMIN, OT_OFF_RUNOFF, OT_OFF_RSTART, OT_OFF_RLEN,
   OT_PROBES, OT_FETCHES, OT_SEED_PROBES, OT_N_FLAGGED, OT_SERIAL,
+  OT_N_ESC = 24,        // 16-bit counts: counts >= 65535 met so far (k_out_scan zeroes it, k_out_pack adds)
   OT_WORDS = 32
 };
+constexpr uint32_t OUT_ESC_CAP = 2048;   // exact counts the escape list of one delivery holds
 
 constexpr uint32_t OUT_SCAN_THREADS = 256;
 
@@ -53,6 +57,7 @@ struct OutArgs {
   uint32_t n_targets;
   uint32_t ran_graph;
   uint32_t lean;                       // omit the node counts of bare-reference targets
+  uint32_t count16;                    // node counts as 16-bit values + escape list
   unsigned long long serial;           // stamped into totals[OT_SERIAL]: which run this delivery belongs to
   // walk / graph results
   const uint32_t* status;
@@ -94,6 +99,8 @@ struct OutArgs {
   uint64_t* o_extra_off;
   uint32_t* o_path_off;
   uint32_t* o_refmax;
+  uint64_t* o_esc_node;                // [OUT_ESC_CAP]
+  uint32_t* o_esc_value;               // [OUT_ESC_CAP]
   unsigned char* tail;
   uint64_t tail_cap;
 };
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(OUT_SCAN_THREADS) void k_out_scan(OutArgs a) {
   const uint32_t n = a.n_targets;
   const uint32_t t = blockIdx.x * OUT_SCAN_THREADS + tid;
   if (tid < 4) stat[tid] = 0;
+  if (t == 0) a.totals[OT_N_ESC] = 0;                      // (k_out_pack counts into it)
   __syncthreads();
   unsigned long long s[4] = {0, 0, 0, 0};
   unsigned long long probes = 0, fetches = 0, seedp = 0;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
     tot[4] = g1.x; tot[5] = g1.y; tot[6] = g1.z; tot[7] = g1.w;
   }
   uint64_t o = 0;
-  const uint64_t off_count = o;  o = out_align(o + 4 * tot[0]);
+  const uint64_t off_count = o;  o = out_align(o + (a.count16 ? 2 : 4) * tot[0]);
   const uint64_t off_extra = o;  o = out_align(o + 8 * tot[1]);
   const uint64_t off_plen = o;   o = out_align(o + 4 * tot[2]);
   const uint64_t off_pmin = o;   o = out_align(o + 4 * tot[2]);
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
     T[OT_PROBES] = tot[4]; T[OT_FETCHES] = tot[5]; T[OT_SEED_PROBES] = tot[6];
     T[OT_N_FLAGGED] = *a.n_flagged;
     T[OT_SERIAL] = a.serial;
-    for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) T[q] = 0;
+    for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) if (q != OT_N_ESC) T[q] = 0;
     a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
   }
   if (nh) return;                        // the host finishes the batch and delivers again
@@ -302,7 +310,25 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
   uint32_t* o_rs = reinterpret_cast<uint32_t*>(a.tail + off_rstart);
   uint32_t* o_rl = reinterpret_cast<uint32_t*>(a.tail + off_rlen);
   // ---- nodes (four independent loads per lane in flight)
-  {
+  if (a.count16) {
+    const uint32_t* src = a.node_cnt + nb;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(a.tail + off_count) + n0;
+    for (uint32_t i0 = lane; i0 < nn; i0 += 256) {
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) v[u] = (i0 + 64 * u < nn) ? src[i0 + 64 * u] : 0u;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        if (i0 + 64 * u >= nn) continue;
+        if (v[u] >= 0xFFFFu) {                              // the exact value goes on the escape list
+          const unsigned long long at = atomicAdd(&a.totals[OT_N_ESC], 1ull);
+          if (at < OUT_ESC_CAP) { a.o_esc_node[at] = n0 + i0 + 64 * u; a.o_esc_value[at] = v[u]; }
+          v[u] = 0xFFFFu;
+        }
+        dst[i0 + 64 * u] = (uint16_t)v[u];
+      }
+    }
+  } else {
     const uint32_t* src = a.node_cnt + nb;
     uint32_t* dst = o_cnt + n0;
     for (uint32_t i0 = lane; i0 < nn; i0 += 256) {

@@ -728,7 +728,7 @@ constexpr uint32_t FAST_BCAP_MAX = 512;       // branch frames the fast tier kee
 constexpr uint32_t FAST_FCAP_MAX = 4096;      // stack frames per target in the fast tier's scratch
 
 // Region A of the delivery buffer (deliver_kernel.h): offsets from n_targets alone.
-struct OutLayout { uint64_t totals, status, n_ref, probes, node_off, extra_off, path_off, ref_max, a_bytes; };
+struct OutLayout { uint64_t totals, status, n_ref, probes, node_off, extra_off, path_off, ref_max, esc_node, esc_value, a_bytes; };
 OutLayout out_layout(uint32_t n) {
   auto al = [](uint64_t v) { return (v + 63) & ~63ull; };
   OutLayout L;
@@ -741,6 +741,8 @@ OutLayout out_layout(uint32_t n) {
   L.extra_off = o; o = al(o + 8ull * ((uint64_t)n + 1));
   L.path_off = o;  o = al(o + 4ull * ((uint64_t)n + 1));
   L.ref_max = o;   o = al(o + 4ull * n);
+  L.esc_node = o;  o = al(o + 8ull * OUT_ESC_CAP);
+  L.esc_value = o; o = al(o + 4ull * OUT_ESC_CAP);
   L.a_bytes = o;
   return L;
 }
@@ -814,6 +816,7 @@ struct km_batch {
   hipEvent_t ev_out = nullptr;
   bool deliver_pending = false, result_ready = false;
   bool lean = false;                  // the pending / ready delivery omits bare-reference node counts
+  bool count16 = false;               // ... and carries 16-bit counts + escape list (KM_DELIVER_COUNT16)
   uint64_t copied_tail = 0, tail_guess = 0;
   unsigned long long serial = 0;
   std::vector<uint64_t> h_packed;     // km_batch_fetch: packed targets, when node_kmer is asked for
@@ -1268,10 +1271,11 @@ static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
 
 // Compaction kernels + ONE asynchronous copy of region A and the expected part of the tail into
 // the pinned twin; km_batch_result() waits for ev_out and fetches what the guess left behind.
-static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
+static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean, bool count16 = false) {
   const double h_in = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
   const uint32_t n = b->n_targets;
   b->lean = lean;
+  b->count16 = count16;
   const OutLayout L = out_layout(n);
   b->result_ready = false;
   if (n == 0) {
@@ -1288,6 +1292,7 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.n_targets = n;
   oa.ran_graph = (b->ran_graph && b->graph_mode == 0) ? 1u : 0u;
   oa.lean = lean ? 1u : 0u;
+  oa.count16 = count16 ? 1u : 0u;
   oa.serial = ++b->serial;
   oa.status = b->d_status.p; oa.g_status = b->d_gstatus.p; oa.n_nodes = b->d_n_nodes.p; oa.n_ref = b->d_n_ref.p;
   oa.t_npaths = b->d_npaths.p; oa.t_pathbase = b->d_pathbase.p; oa.t_nruns = b->d_t_nruns.p;
@@ -1314,6 +1319,8 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean) {
   oa.o_extra_off = reinterpret_cast<uint64_t*>(dst + L.extra_off);
   oa.o_path_off = reinterpret_cast<uint32_t*>(dst + L.path_off);
   oa.o_refmax = reinterpret_cast<uint32_t*>(dst + L.ref_max);
+  oa.o_esc_node = reinterpret_cast<uint64_t*>(dst + L.esc_node);
+  oa.o_esc_value = reinterpret_cast<uint32_t*>(dst + L.esc_value);
   oa.tail = dst + L.a_bytes;
   oa.tail_cap = b->out_cap - L.a_bytes;
   const int dbg_deliver = knobs().debug_deliver;   // timing ablations (diagnostics build only)
@@ -1371,6 +1378,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   const bool want_graph = (stages & KM_RUN_HIPGRAPH) != 0;
   const bool want_deliver = (stages & KM_RUN_DELIVER) != 0;
   const bool want_lean = (stages & KM_DELIVER_LEAN) != 0;
+  const bool want_c16 = (stages & KM_DELIVER_COUNT16) != 0;
   const bool want_timed = (stages & KM_RUN_TIMED) != 0;
   const bool serial = (stages & KM_RUN_SERIAL) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
@@ -1382,7 +1390,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     b->ran_graph = (stages & KM_STAGE_GRAPH) != 0;
     b->graph_mode = b->ran_graph ? 0 : 1;
     b->synced = true;
-    return want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
+    return want_deliver ? enqueue_deliver(b, st, want_lean, want_c16) : KM_OK;
   }
   {
     int rc = restore_layout(b, st);
@@ -1395,7 +1403,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     b->ran_graph = true;
     b->synced = false;
     b->timed = false;
-    return want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
+    return want_deliver ? enqueue_deliver(b, st, want_lean, want_c16) : KM_OK;
   }
 
   b->graph_mode = (stages & KM_STAGE_GRAPH) ? 0 : 1;
@@ -1491,7 +1499,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   if (host_trace) {
     ht[4] = host_now_us();
   }
-  const int rc_deliver = want_deliver ? enqueue_deliver(b, st, want_lean) : KM_OK;
+  const int rc_deliver = want_deliver ? enqueue_deliver(b, st, want_lean, want_c16) : KM_OK;
   if (host_trace)
     fprintf(stderr, "[km host] run: setdevice+layout %.1f us, geometry %.1f, memset %.1f, launches %.1f, delivery %.1f, whole call %.1f\n",
             ht[1] - ht[0], ht[2] - ht[1], ht[3] - ht[2], ht[4] - ht[3], host_now_us() - ht[4], host_now_us() - ht[0]);
@@ -1733,10 +1741,11 @@ static hipError_t wait_event_hot(hipEvent_t ev) {
 // `need_full`: a lean delivery (pending or ready) is replaced by a full one.
 static int finish_result(km_batch* b, bool need_full) {
   if (!b->ran_walk) return fail(KM_E_STATE, "nothing has run yet");
-  if (b->result_ready && !(need_full && b->lean)) return KM_OK;
+  const bool partial = b->lean || b->count16;       // the pending / ready delivery is not the full 32-bit form
+  if (b->result_ready && !(need_full && partial)) return KM_OK;
   HIPCHK(hipSetDevice(b->device));
   hipStream_t st = b->last_stream;
-  if (need_full && b->lean && (b->deliver_pending || b->result_ready)) {
+  if (need_full && partial && (b->deliver_pending || b->result_ready)) {
     HIPCHK(hipEventSynchronize(b->ev_out));
     b->deliver_pending = b->result_ready = false;
   }
@@ -1756,6 +1765,13 @@ static int finish_result(km_batch* b, bool need_full) {
     }
     if (T[OT_SERIAL] != b->serial) return fail(KM_E_HIP, "delivery buffer out of step");
     const unsigned long long nh = T[OT_NEEDS_HOST];
+    if (!nh && b->count16 && T[OT_N_ESC] > OUT_ESC_CAP) {
+      // more counts >= 65535 than the escape list holds: this batch is delivered with 32-bit counts
+      if (attempt >= 4) return fail(KM_E_NOMEM, "result delivery keeps failing");
+      int rc = enqueue_deliver(b, st, b->lean, false);
+      if (rc != KM_OK) return rc;
+      continue;
+    }
     if (!nh) break;
     if (attempt >= 4) return fail(KM_E_NOMEM, "result delivery keeps failing");
     if (nh & 1ull) {
@@ -1774,7 +1790,7 @@ static int finish_result(km_batch* b, bool need_full) {
       if (rc != KM_OK) return rc;
     }
     T = reinterpret_cast<const unsigned long long*>(b->h_out + L.totals);
-    int rc = enqueue_deliver(b, st, b->lean);
+    int rc = enqueue_deliver(b, st, b->lean, b->count16);
     if (rc != KM_OK) return rc;
   }
   const uint64_t tail = T[OT_TAIL_BYTES];
@@ -1782,6 +1798,16 @@ static int finish_result(km_batch* b, bool need_full) {
     HIPCHK(hipMemcpy(b->h_out + L.a_bytes + b->copied_tail, b->d_out + L.a_bytes + b->copied_tail,
                      tail - b->copied_tail, hipMemcpyDeviceToHost));
   b->tail_guess = tail + tail / 16 + 4096;
+  if (b->count16 && T[OT_N_ESC] > 1) {
+    // the escape list in node order (the delivery kernel appends as its waves come)
+    const uint32_t ne = (uint32_t)T[OT_N_ESC];
+    uint64_t* en = reinterpret_cast<uint64_t*>(b->h_out + L.esc_node);
+    uint32_t* ev = reinterpret_cast<uint32_t*>(b->h_out + L.esc_value);
+    std::vector<std::pair<uint64_t, uint32_t>> tmp(ne);
+    for (uint32_t i = 0; i < ne; ++i) tmp[i] = {en[i], ev[i]};
+    std::sort(tmp.begin(), tmp.end());
+    for (uint32_t i = 0; i < ne; ++i) { en[i] = tmp[i].first; ev[i] = tmp[i].second; }
+  }
   b->deliver_pending = false;
   b->result_ready = true;
   return KM_OK;
@@ -1800,7 +1826,13 @@ static void view_of_result(const km_batch* b, km_batch_out_t* v) {
   v->extra_off = reinterpret_cast<uint64_t*>(h + L.extra_off);
   v->path_off = reinterpret_cast<uint32_t*>(h + L.path_off);
   v->ref_max_cov = reinterpret_cast<uint32_t*>(h + L.ref_max);
-  v->node_count = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_COUNT]);
+  if (b->count16) {
+    v->node_count16 = reinterpret_cast<uint16_t*>(tail + T[OT_OFF_COUNT]);
+    v->count_esc_node = reinterpret_cast<uint64_t*>(h + L.esc_node);
+    v->count_esc_value = reinterpret_cast<uint32_t*>(h + L.esc_value);
+  } else {
+    v->node_count = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_COUNT]);
+  }
   v->extra_kmer = reinterpret_cast<uint64_t*>(tail + T[OT_OFF_EXTRA]);
   v->path_len = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_PLEN]);
   v->path_min_cov = reinterpret_cast<uint32_t*>(tail + T[OT_OFF_PMIN]);
@@ -1822,6 +1854,7 @@ static void sizes_of_result(const km_batch* b, km_batch_sizes_t* s) {
   s->n_big_tier = b->n_big;
   s->n_flagged = (uint32_t)T[OT_N_FLAGGED];
   s->seed_probes = T[OT_SEED_PROBES];
+  s->n_count_escapes = b->count16 ? (uint32_t)T[OT_N_ESC] : 0;
 }
 
 extern "C" int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes) {

@@ -237,6 +237,7 @@ struct RowRec {
 struct Scratch {
   std::vector<Path> paths;
   std::vector<uint32_t> min_cov;
+  std::vector<uint32_t> counts32;      // a target's counts when the view carries them as 16-bit values
   std::vector<uint64_t> prefix;        // prefix[i] = sum of the float32 values of the counts of nodes < i
   Path ref, cref;
   struct Event { int64_t pos; int32_t c, d; };
@@ -832,8 +833,13 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
                               int32_t** err_out) {
   if (!in || !text_out || !row_off_out || !err_out || !in->res) return KM_E_ARG;
   const km_batch_out_t& r = *in->res;
+  // counts: 32-bit, or 16-bit + the list of the exact counts >= 65535 (KM_DELIVER_COUNT16; the list's length is
+  // in the sizes, so those are required then)
+  const bool c16 = !r.node_count && r.node_count16;
+  const uint32_t n_esc = c16 && in->sizes ? in->sizes->n_count_escapes : 0;
+  if (c16 && (!in->sizes || (n_esc && (!r.count_esc_node || !r.count_esc_value)))) return KM_E_ARG;
   if (!r.status || !r.n_ref || !r.node_off || (!r.node_kmer && (!r.extra_off || !r.extra_kmer)) ||
-      !r.node_count || !r.path_off || !r.run_off ||
+      (!r.node_count && !r.node_count16) || !r.path_off || !r.run_off ||
       !r.run_start || !r.run_len || !r.path_min_cov || (in->n_targets && (!in->bases || !in->base_off || !in->names)))
     return KM_E_ARG;
   if (in->k < 2 || in->k > 32) return KM_E_K;
@@ -856,6 +862,8 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
     }
     for (uint32_t p = 0; p < z.n_paths; ++p)
       if (r.run_off[p + 1] < r.run_off[p]) return KM_E_ARG;
+    for (uint32_t q = 0; q < n_esc; ++q)
+      if (r.count_esc_node[q] >= z.n_nodes || (q && r.count_esc_node[q] <= r.count_esc_node[q - 1])) return KM_E_ARG;
   }
   uint64_t* row_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n + 1));
   int32_t* err = (int32_t*)malloc(sizeof(int32_t) * std::max<size_t>(1, n));
@@ -903,7 +911,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
             t.n_ref = r.n_ref[ti];
             t.kmers = r.node_kmer ? r.node_kmer + r.node_off[ti] : nullptr;
             t.extra = r.node_kmer ? nullptr : r.extra_kmer + r.extra_off[ti];
-            t.counts = r.node_count + r.node_off[ti];
+            t.counts = r.node_count ? r.node_count + r.node_off[ti] : nullptr;
             // ---- this target's slice of the view must hang together before any of it is used
             if (r.node_off[ti + 1] < r.node_off[ti] || r.path_off[ti + 1] < r.path_off[ti] ||
                 in->base_off[ti + 1] < in->base_off[ti]) { err[ti] = 5; continue; }
@@ -917,6 +925,18 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
               t.n_nodes = t.n_ref;
             }
             if (t.n_nodes < t.n_ref || (int64_t)t.seq_len < t.n_ref + t.k - 1) { err[ti] = 5; continue; }
+            if (c16 && !lean) {
+              // 16-bit counts: this target's as 32-bit values, the exact ones patched in from the escape list
+              const uint64_t n0 = r.node_off[ti], n1 = r.node_off[ti + 1];
+              w.counts32.resize((size_t)t.n_nodes);
+              for (int64_t i = 0; i < t.n_nodes; ++i) w.counts32[(size_t)i] = r.node_count16[n0 + (uint64_t)i];
+              if (n_esc) {
+                const uint64_t* e0 = r.count_esc_node;
+                for (const uint64_t* e = std::lower_bound(e0, e0 + n_esc, n0); e < e0 + n_esc && *e < n1; ++e)
+                  w.counts32[(size_t)(*e - n0)] = r.count_esc_value[e - e0];
+              }
+              t.counts = w.counts32.data();
+            }
             if (!r.node_kmer) {
               if (r.extra_off[ti + 1] < r.extra_off[ti] ||
                   (int64_t)(r.extra_off[ti + 1] - r.extra_off[ti]) != t.n_nodes - t.n_ref) { err[ti] = 5; continue; }

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("KM_LIBRARY") or os.path.join(_HERE, "libkmgpu.so")
 
 KM_OK = 0
 KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER, KM_DELIVER_LEAN, KM_RUN_TIMED = 1, 2, 4, 8, 16, 32
+KM_DELIVER_COUNT16 = 128        # node counts cross PCIe as 16-bit values + the list of the exact counts >= 65535
 KM_RUN_SERIAL = 64
 T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 
@@ -56,9 +57,11 @@ class BatchSizes(C.Structure):
     _fields_ = [("n_targets", C.c_uint32), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint64),
                 ("n_runs", C.c_uint64), ("logical_probes", C.c_uint64),
                 ("table_fetches", C.c_uint64), ("n_big_tier", C.c_uint32), ("n_flagged", C.c_uint32),
-                ("seed_probes", C.c_uint64), ("n_extra", C.c_uint64)]
+                ("seed_probes", C.c_uint64), ("n_extra", C.c_uint64),
+                ("n_count_escapes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+_P16 = C.POINTER(C.c_uint16)
 _P32 = C.POINTER(C.c_uint32)
 _P64 = C.POINTER(C.c_uint64)
 
@@ -68,7 +71,8 @@ class BatchOut(C.Structure):
                 ("node_off", _P64), ("node_kmer", _P64), ("node_count", _P32),
                 ("path_off", _P32), ("run_off", _P64), ("run_start", _P32), ("run_len", _P32),
                 ("path_len", _P32), ("path_min_cov", _P32), ("extra_off", _P64), ("extra_kmer", _P64),
-                ("ref_max_cov", _P32)]
+                ("ref_max_cov", _P32),
+                ("node_count16", _P16), ("count_esc_node", _P64), ("count_esc_value", _P32)]
 
 
 class ReportIn(C.Structure):
@@ -472,12 +476,22 @@ class Batch:
                 return np.zeros(0, dtype)
             return np.ctypeslib.as_array(p, shape=(int(count),))
 
-        return {
+        extra = {}
+        if not out.node_count and out.node_count16:
+            # KM_DELIVER_COUNT16: the 16-bit form as delivered, and the counts as every consumer here reads them
+            c16 = view(out.node_count16, s.n_nodes, np.uint16)
+            esc_n = view(out.count_esc_node, s.n_count_escapes, np.uint64)
+            esc_v = view(out.count_esc_value, s.n_count_escapes, np.uint32)
+            counts = c16.astype(np.uint32)
+            if s.n_count_escapes:
+                counts[esc_n.astype(np.int64)] = esc_v
+            extra = {"node_count16": c16, "count_esc_node": esc_n, "count_esc_value": esc_v, "node_count": counts}
+        res = {
             "status": view(out.status, n, np.uint32), "n_ref": view(out.n_ref, n, np.uint32),
             "probes": view(out.probes, n, np.uint64), "node_off": view(out.node_off, n + 1, np.uint64),
             "extra_off": view(out.extra_off, n + 1, np.uint64),
             "ref_max_cov": view(out.ref_max_cov, n, np.uint32),
-            "node_count": view(out.node_count, s.n_nodes, np.uint32),
+            "node_count": extra["node_count"] if extra else view(out.node_count, s.n_nodes, np.uint32),
             "extra_kmer": view(out.extra_kmer, s.n_extra, np.uint64),
             "path_off": view(out.path_off, n + 1, np.uint32),
             "run_off": view(out.run_off, s.n_paths + 1, np.uint64),
@@ -488,6 +502,8 @@ class Batch:
             "logical_probes": int(s.logical_probes), "table_fetches": int(s.table_fetches),
             "n_big_tier": int(s.n_big_tier), "n_flagged": int(s.n_flagged),
         }
+        res.update(extra)
+        return res
 
     def fetch(self, nodes=True, paths=True):
         """Copy results to host numpy arrays (dict), node k-mers rebuilt in full."""
@@ -611,11 +627,22 @@ def report_text(res, names, seqs, k, db_name, packed=None):
                          ("extra_off", C.c_uint64), ("extra_kmer", C.c_uint64), ("ref_max_cov", C.c_uint32)):
         if field not in res:
             continue                                   # a delivery view has no node_kmer, a fetch no extra_*
+        if field == "node_count" and "node_count16" in res:
+            continue                                   # the 16-bit form goes to the library as it came
         arr = np.ascontiguousarray(res[field], dtype=np.dtype(ctype))
         if arr.size == 0:
             arr = np.zeros(1, dtype=arr.dtype)
         keep.append(arr)
         setattr(out, field, typed_ptr(arr, ctype))
+    n_esc = 0
+    if "node_count16" in res:
+        n_esc = int(np.asarray(res["count_esc_node"]).size)
+        for field, ctype in (("node_count16", C.c_uint16), ("count_esc_node", C.c_uint64), ("count_esc_value", C.c_uint32)):
+            arr = np.ascontiguousarray(res[field], dtype=np.dtype(ctype))
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=arr.dtype)
+            keep.append(arr)
+            setattr(out, field, typed_ptr(arr, ctype))
     inp = ReportIn()
     inp.n_targets = n
     inp.bases = blob.ctypes.data
@@ -632,6 +659,7 @@ def report_text(res, names, seqs, k, db_name, packed=None):
     sz.n_paths = int(np.asarray(res["path_min_cov"]).size)
     sz.n_runs = int(np.asarray(res["run_start"]).size)
     sz.n_extra = int(np.asarray(res["extra_kmer"]).size) if "extra_kmer" in res else 0
+    sz.n_count_escapes = n_esc
     inp.sizes = C.pointer(sz)
     text = C.c_void_p()
     row_off = C.POINTER(C.c_uint64)()

@@ -50,9 +50,24 @@ static T* dup(const std::vector<T>& v) {
   return p;
 }
 
-static int run(const View& v, bool with_sizes, int* n_err5, int* n_rows, const char* label) {
+static uint64_t g_text_hash = 0;          // FNV-1a of the text of the last served call
+// as16: 0 = 32-bit counts; 1 = 16-bit counts + escape list; 2 = ... with the list out of order; 3 = ... with an
+// entry beyond the nodes
+static int run(const View& v, bool with_sizes, int* n_err5, int* n_rows, const char* label, int as16 = 0) {
   km_batch_out_t out;
   memset(&out, 0, sizeof out);
+  std::vector<uint16_t> c16;
+  std::vector<uint64_t> esc_n;
+  std::vector<uint32_t> esc_v;
+  if (as16) {
+    for (size_t i = 0; i < v.node_count.size(); ++i) {
+      const uint32_t c = v.node_count[i];
+      c16.push_back((uint16_t)(c >= 0xFFFFu ? 0xFFFFu : c));
+      if (c >= 0xFFFFu) { esc_n.push_back(i); esc_v.push_back(c); }
+    }
+    if (as16 == 2 && esc_n.size() >= 2) std::swap(esc_n[0], esc_n[1]);
+    if (as16 == 3 && !esc_n.empty()) esc_n.back() = v.node_count.size() + 7;
+  }
   out.status = dup(v.status); out.n_ref = dup(v.n_ref); out.node_off = dup(v.node_off);
   out.node_count = dup(v.node_count); out.extra_off = dup(v.extra_off); out.extra_kmer = dup(v.extra_kmer);
   out.path_off = dup(v.path_off); out.run_off = dup(v.run_off); out.run_start = dup(v.run_start);
@@ -65,6 +80,14 @@ static int run(const View& v, bool with_sizes, int* n_err5, int* n_rows, const c
   memset(&sz, 0, sizeof sz);
   sz.n_targets = v.n; sz.n_nodes = v.node_count.size(); sz.n_paths = (uint32_t)v.path_min_cov.size();
   sz.n_runs = v.run_start.size(); sz.n_extra = v.extra_kmer.size();
+  uint16_t* d16 = nullptr; uint64_t* den = nullptr; uint32_t* dev = nullptr;
+  if (as16) {
+    free(out.node_count);
+    out.node_count = nullptr;
+    d16 = dup(c16); den = dup(esc_n); dev = dup(esc_v);
+    out.node_count16 = d16; out.count_esc_node = den; out.count_esc_value = dev;
+    sz.n_count_escapes = (uint32_t)esc_n.size();
+  }
   km_report_in_t in;
   memset(&in, 0, sizeof in);
   in.n_targets = v.n; in.bases = bases; in.base_off = base_off; in.names = names.data(); in.db_name = "view.jf";
@@ -76,13 +99,14 @@ static int run(const View& v, bool with_sizes, int* n_err5, int* n_rows, const c
   *n_err5 = 0; *n_rows = 0;
   if (rc == KM_OK) {
     for (uint32_t t = 0; t < v.n; ++t) *n_err5 += err[t] == 5;
-    for (uint64_t i = 0; i < row_off[v.n]; ++i) *n_rows += text[i] == '\n';
+    g_text_hash = 1469598103934665603ull;
+    for (uint64_t i = 0; i < row_off[v.n]; ++i) { *n_rows += text[i] == '\n'; g_text_hash = (g_text_hash ^ (unsigned char)text[i]) * 1099511628211ull; }
     km_report_free(text, row_off, err);
   }
   printf("%-44s sizes=%d rc=%d err5=%d rows=%d\n", label, (int)with_sizes, rc, *n_err5, *n_rows);
   free(out.status); free(out.n_ref); free(out.node_off); free(out.node_count); free(out.extra_off); free(out.extra_kmer);
   free(out.path_off); free(out.run_off); free(out.run_start); free(out.run_len); free(out.path_min_cov); free(out.ref_max_cov);
-  free(bases); free(base_off);
+  free(bases); free(base_off); free(d16); free(den); free(dev);
   return rc;
 }
 
@@ -160,6 +184,31 @@ int main(int argc, char** argv) {
     bad.extra_off[full.n] += 2;
     rc = run(bad, true, &e5, &rows, "extra_off beyond extra_kmer");
     expect(rc == KM_E_ARG, "KM_E_ARG");
+  }
+  // 7. 16-bit counts + escape list (KM_DELIVER_COUNT16): the same text as the 32-bit form — as delivered (no count
+  // reaches 65535) and with every count times 400 (most do); a list out of order or pointing beyond the nodes is
+  // an argument error
+  {
+    rc = run(full, true, &e5, &rows, "full view");
+    const uint64_t h32 = g_text_hash;
+    rc = run(full, true, &e5, &rows, "full view, 16-bit counts", 1);
+    expect(rc == KM_OK && e5 == 0 && rows == full_rows && g_text_hash == h32, "16-bit counts must give the same text");
+    rc = run(lean, true, &e5, &rows, "lean view, 16-bit counts", 1);
+    expect(rc == KM_OK && e5 == 0 && rows == full_rows && g_text_hash == h32, "lean 16-bit counts must give the same text");
+    View big = lean;
+    size_t over = 0;
+    for (uint32_t& c : big.node_count) { c *= 400u; over += c >= 0xFFFFu; }
+    rc = run(big, true, &e5, &rows, "counts x 400");
+    const uint64_t hbig = g_text_hash;
+    expect(rc == KM_OK && over > 2, "the scaled view must be served and hold escapes");
+    rc = run(big, true, &e5, &rows, "counts x 400, 16-bit + escape list", 1);
+    expect(rc == KM_OK && g_text_hash == hbig, "escaped counts must give the same text");
+    rc = run(big, true, &e5, &rows, "escape list out of order", 2);
+    expect(rc == KM_E_ARG, "KM_E_ARG");
+    rc = run(big, true, &e5, &rows, "escape beyond the nodes", 3);
+    expect(rc == KM_E_ARG, "KM_E_ARG");
+    rc = run(full, false, &e5, &rows, "16-bit counts without the lengths", 1);
+    expect(rc == KM_E_ARG, "KM_E_ARG (the list's length travels in the sizes)");
   }
   printf("%s\n", fails ? "VIEWS FAILED" : "VIEWS OK");
   return fails ? 1 : 0;

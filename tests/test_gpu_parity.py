@@ -806,6 +806,52 @@ def test_delivery_view_equals_fetch():
     assert (np.asarray(w["node_count"]) == v["node_count"]).all() and int(w["path_off"][-1]) == 0
 
 
+def test_sixteen_bit_counts_deliver_the_same_results():
+    """KM_DELIVER_COUNT16: node counts cross PCIe as 16-bit values, a count >= 65535 as 0xFFFF plus its exact value
+    in a short sorted list.  Same counts, same TSV rows as the 32-bit delivery — with no count that large, with a
+    few hundred (some of them on variant paths), and with more than the list holds (then the library delivers the
+    32-bit form by itself)."""
+    case = synth.make_case(n_targets=800, length=400, n_keys=400_000, seed=777, variant_frac=0.5,
+                           variants_per_target=(1, 2), exact_pad=False)
+    seqs = [km.decode(r) for r in case["targets"]]
+    names = list(case["names"])
+    both = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    st = kmlib.stream_create(0)
+    rng = np.random.default_rng(3)
+    for scale_some, expect16 in ((0, True), (300, True), (200_000, False)):
+        counts = case["counts"].copy()
+        if scale_some:
+            # the same k-mers, some counts far beyond 16 bits: (k-1)-mer groups keep their RATIOS only where whole
+            # groups are scaled, so scale every count of a random subset of the targets' neighbourhoods — simply:
+            # every count of a random subset of the records, by the same factor (sibling ratios change for some
+            # groups, which is fine: both deliveries see the same table)
+            pick = rng.random(len(counts)) < (0.002 if scale_some == 300 else 0.5)
+            counts[pick] = np.minimum(counts[pick].astype(np.uint64) * scale_some, 0xFFFFFFF0).astype(np.uint32)
+        db = kmlib.Database.from_records(case["keys"], counts, 31).upload(0)
+        b = kmlib.Batch(db, max_targets=800, max_total_bases=800 * 400)
+        b.set_targets(seqs)
+        b.run(both | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN, st)
+        v32 = {key: (np.array(val) if isinstance(val, np.ndarray) else val) for key, val in b.result().items()}
+        rows32 = kmlib.report_rows(v32, names, seqs, 31, "mem.jf")
+        b.run(both | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN | kmlib.KM_DELIVER_COUNT16, st)
+        v16 = {key: (np.array(val) if isinstance(val, np.ndarray) else val) for key, val in b.result().items()}
+        assert ("node_count16" in v16) == expect16, scale_some
+        for key in ("status", "n_ref", "probes", "node_off", "node_count", "extra_off", "extra_kmer", "path_off",
+                    "run_off", "run_start", "run_len", "path_len", "path_min_cov", "ref_max_cov"):
+            assert (v16[key] == v32[key]).all(), (scale_some, key)
+        if expect16:
+            esc = v16["count_esc_node"]
+            assert (np.diff(esc.astype(np.int64)) > 0).all()
+            assert (v16["node_count16"][esc.astype(np.int64)] == 0xFFFF).all()
+            assert (len(esc) > 20) == (scale_some == 300), len(esc)
+            assert int((v32["node_count"] >= 0xFFFF).sum()) == len(esc)
+        assert kmlib.report_rows(v16, names, seqs, 31, "mem.jf") == rows32       # the 16-bit form goes to the library as it came
+        f = b.fetch()                                                             # the copying API: always 32-bit, in full
+        assert f["node_count"].dtype == np.uint32 and len(f["node_count"]) >= len(v32["node_count"])
+        b.close()
+        db.close()
+
+
 def test_serial_measurement_flag_changes_nothing():
     """KM_RUN_SERIAL only moves k_graph_pure from the side stream behind k_dfs."""
     case = synth.make_case(n_targets=300, length=300, n_keys=60_000, seed=99, variant_frac=0.4)

@@ -120,7 +120,8 @@ int main(int argc, char** argv) {
     CHECK(km_stream_create(0, &streams[(size_t)q]));
     CHECK(km_batch_set_targets(bs[(size_t)q], ascii.data() + (uint64_t)q * T * L, off.data(), T));
   }
-  const int flags = KM_STAGE_WALK | KM_STAGE_GRAPH | KM_RUN_DELIVER | KM_DELIVER_LEAN;
+  const int flags = KM_STAGE_WALK | KM_STAGE_GRAPH | KM_RUN_DELIVER | KM_DELIVER_LEAN |
+                    (getenv("KMCLIENT_COUNT32") ? 0 : KM_DELIVER_COUNT16);
 
   if (mode == "pump") {
     CHECK(km_batch_pump(bs.data(), streams.data(), n_fl, warmup > n_fl ? warmup : n_fl, flags));
