@@ -707,9 +707,9 @@ def main():
             batches[q].set_targets_dev(bases_all[lo:lo + Ts].data_ptr(), offs_s, stream)
         device_sync()
         pipeline(n_fl, deliver, True)
-        dts = timed(deliver, True)
-        strong = {"targets_total": Ts * world, "targets_per_gpu": Ts, "ms_per_step": dts / args.steps * 1e3,
-                  "value": Ts * world / (dts / args.steps), "unit": "targets/s", "scaling": "strong"}
+        dt_strong = timed(deliver, True)
+        strong = {"targets_total": Ts * world, "targets_per_gpu": Ts, "ms_per_step": dt_strong / args.steps * 1e3,
+                  "value": Ts * world / (dt_strong / args.steps), "unit": "targets/s", "scaling": "strong"}
         for q in range(n_fl):
             batches[q].set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
 
