@@ -1166,6 +1166,34 @@ def test_cli_two_ranks_target_sharded(tmp_path):
         assert got == t["stream"], name
 
 
+def test_bench_line_at_two_ranks():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU): one JSON line from
+    rank 0 with the contract's keys, the weak-scaling workload named, both ranks seen, its in-run oracle check
+    green.  On a one-GPU box both ranks share device 0 over gloo (--one-gpu: a rehearsal of the flow, not a number).
+    Round 3 shipped a rank-0 crash here for an hour: the strong-scaling side figure overwrote the list of timings."""
+    import subprocess
+    import sys
+    import torch
+    two = torch.cuda.device_count() >= 2
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2",
+           "--steps", "6", "--warmup", "2", "--keys", "3000000", "--targets", "2000", "--no-cpu", "--e2e", "0",
+           "--no-ingest", "--no-hard", "--repeats", "2"] + ([] if two else ["--one-gpu", "--backend", "gloo"])
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["ranks_seen"]["world_size"] == 2 and len(d["ranks_seen"]["devices"]) == 2
+    assert d["oracle_check"]["ok"] and d["config4_strong"]["scaling"] == "strong"
+    assert d["timed_region"]["repeats"] == 2
+
+
 def test_config5_synthetic_samples_match_oracle(tmp_path):
     """BASELINE config 5: the 9-target catalog against synthetic per-sample tables (seed = sample
     index, km_amd.synth.make_sample) through km_amd.dist.sample_matrix; every row of every
