@@ -412,11 +412,8 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     if (n && meta[6] && meta[6] <= SETTLE_CAP && !getenv("KM_TABLE_NO_SETTLE")) {
       const uint32_t n_list = (uint32_t)meta[6];
       const uint32_t lds = 128u << 10;
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_table_settle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-      }
+      // (per device and cheap: set on every build rather than remembered per process)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_table_settle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       const uint32_t race_probe = max_probe;
       const unsigned long long n_slots_total = meta[5];
       (void)hipMemsetAsync(d_meta + 3, 0, 8, st);
