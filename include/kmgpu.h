@@ -61,7 +61,9 @@ typedef struct {
   uint64_t table_bytes;  /* n_slots * 16 + bucket directory + side table of counts >= 65535 */
   int32_t  device;       /* HIP device ordinal of the table, -1 if none       */
   int32_t  max_probe;    /* slots a lookup may read: 2 (the home pair) unless a minimizer
-                            bucket was too heavy to keep that bound            */
+                            bucket was too heavy to keep that bound; like n_slots a function of
+                            the record SET (any order of the records gives the same table
+                            geometry: the build's settle pass)    */
 } kmjf_info_t;
 
 /* Walk parameters = the CLI flags of km/argparser/find_mutation.py:5-39 as they
