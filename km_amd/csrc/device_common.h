@@ -69,7 +69,8 @@ struct TableView {
   uint64_t n_ovf;
   uint64_t kmask;        // 2k low bits set
   uint64_t pmask;        // 2(k-1) low bits set
-  uint32_t n_buckets;
+  uint32_t n_buckets;    // a power of two
+  uint32_t bshift;       // 32 - log2(n_buckets): bucket = hash >> bshift
   uint32_t unit;         // slots per entry when sizing a bucket (2 = load factor <= 0.5)
   uint32_t cshift;       // log2(NC), NC = power of two >= 2w: class-mode buckets hold q * NC slots
   uint32_t max_probe;    // every stored key sits within this many slots of its home (2: the home pair)
@@ -167,8 +168,10 @@ __host__ __device__ inline uint32_t window_key(const TableView& t, uint64_t P, u
   return (mm_order(c) & ~SEL_POS) | (uint32_t)j;
 }
 
+// floor(hash / 2^32 * n_buckets) — n_buckets is a power of two, so that is a shift (a 32-bit multiply-high is a
+// quarter-rate instruction, and k_seed is where the pipelined step's issue slots go)
 __host__ __device__ inline uint32_t bucket_of(const TableView& t, uint32_t canon_mmer) {
-  return (uint32_t)(((uint64_t)mm_bucket(canon_mmer) * t.n_buckets) >> 32);
+  return mm_bucket(canon_mmer) >> t.bshift;
 }
 __host__ __device__ inline void finish_key(const TableView& t, uint64_t P, uint64_t R, uint32_t c,
                                            uint32_t s, uint32_t u, Key* key) {
@@ -306,16 +309,18 @@ __device__ inline uint32_t pick4(uint4 v, uint32_t i) {
 // PAIR (home, home + 1) is one aligned 32-byte piece of a line, and the build guarantees that
 // every key sits inside its home pair (a bucket that cannot is doubled until it can).
 __device__ inline uint64_t home_slot(const TableView& t, const Key& key, uint64_t S) {
-  const uint64_t q = S >> t.cshift;
-  if (q) {
-    // odd multiple of NC: a crowded bucket (many near-identical super-k-mers behind one
-    // minimizer pile up in a few classes) — plain hashing over all its pairs
-    if (q & 1) return (uint64_t)__umulhi(key.hsub, (uint32_t)(S >> 1)) << 1;
-    // class mode: S = q * NC, q even; the class owns q slots
-    return (uint64_t)key.cls * q + (__umulhi(key.hsub, (uint32_t)q) & ~1u);
-  }
-  // small bucket: floor(frac / 2^32 * S), order preserving
-  return (uint64_t)(__umulhi(key.frac, (uint32_t)S) & ~1u);
+  // Three layouts, one multiply: the lanes of a wave meet all three (as branches every lane paid for all of them)
+  //  small bucket (S < NC): floor(frac / 2^32 * S), order preserving
+  //  crowded bucket (an odd multiple of NC: many near-identical super-k-mers behind one minimizer pile up in a
+  //                  few classes): plain hashing over all its pairs
+  //  class mode (S = q * NC, q even): the class owns q slots
+  const uint32_t q = (uint32_t)(S >> t.cshift);
+  const bool small = q == 0, crowded = (q & 1u) != 0;
+  const uint32_t h = small ? key.frac : key.hsub;
+  const uint32_t n = small ? (uint32_t)S : (crowded ? (uint32_t)(S >> 1) : q);
+  const uint32_t m = __umulhi(h, n);
+  const uint64_t in_class = (uint64_t)key.cls * q + (m & ~1u);
+  return small ? (uint64_t)(m & ~1u) : (crowded ? ((uint64_t)m << 1) : in_class);
 }
 // Two-choice probing: a key whose home pair is taken moves to a SECOND pair of its bucket, chosen
 // by an independent hash, and only from there on probes linearly (insert and lookup follow the
@@ -502,7 +507,7 @@ struct BucketLanes {
 };
 struct ChildRule {       // what get_child needs beside the counts (wave-uniform)
   double ratio;
-  int64_t n_cutoff;
+  double nc;             // (double)n_cutoff
   uint64_t thr_below;    // sums below it share the threshold thr_T (threshold_shortcut)
   uint32_t thr_T;
 };
@@ -615,21 +620,29 @@ __device__ inline uint32_t query_one(const TableView& t, uint64_t X, uint32_t* f
 // km/utils/Jellyfish.py:69-72.  Returns a 4-bit mask, bit c = child base c.
 // The threshold as an integer: a count is kept iff it is >= T, unless *none (the threshold lies
 // above every 32-bit count, or is NaN).
-__host__ __device__ inline uint32_t child_threshold(uint64_t sum, double ratio, int64_t n_cutoff, bool* none) {
-  const double t = (double)sum * ratio;
-  const double nc = (double)n_cutoff;
+// (nc = (double)n_cutoff, converted once by the caller: the kernels get it as a kernel argument — there is no scalar
+// int64 -> double conversion, so every lane would do it)
+__host__ __device__ inline uint32_t threshold_of(double t, double nc, bool* none) {
   const double thr = (nc > t) ? nc : t;     // Python max(t, nc)
   // an integer count is >= thr  <=>  it is >= ceil(thr): four integer compares
   const double ct = ceil(thr);
   *none = !(ct < 4294967296.0);
   return ct <= 0.0 ? 0u : (*none ? 0xFFFFFFFFu : (uint32_t)ct);
 }
-__device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) {
+__host__ __device__ inline uint32_t child_threshold(uint64_t sum, double ratio, int64_t n_cutoff, bool* none) {
+  return threshold_of((double)sum * ratio, (double)n_cutoff, none);
+}
+__device__ inline uint32_t child_mask(uint4 c, double ratio, double nc) {
   bool none;
-  const uint32_t T = child_threshold((uint64_t)c.x + c.y + c.z + c.w, ratio, n_cutoff, &none);
+  uint32_t T;
+  // the sum of four counts fits 32 bits unless one of them came from the side table of large counts (>= 2^30,
+  // conservatively): one conversion instead of two + ldexp + add, the same double either way
+  if (!__any((int)(((c.x | c.y | c.z | c.w) >> 30) != 0))) T = threshold_of((double)(c.x + c.y + c.z + c.w) * ratio, nc, &none);
+  else T = threshold_of((double)((uint64_t)c.x + c.y + c.z + c.w) * ratio, nc, &none);
   if (none) return 0u;
   return (c.x >= T ? 1u : 0u) | (c.y >= T ? 2u : 0u) | (c.z >= T ? 4u : 0u) | (c.w >= T ? 8u : 0u);
 }
+__device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) { return child_mask(c, ratio, (double)n_cutoff); }
 // device_common.h: BucketLanes.  What Jellyfish.get_child (km/utils/Jellyfish.py:55-72) makes of one
 // slot, for the k-mers x whose suffix x[1:] is the slot's (k-1)-mer in the orientation its side bit names.
 __device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
@@ -640,7 +653,7 @@ __device__ inline void slot_successor(const TableView& t, const ChildRule& r, ui
   const uint64_t sum = (uint64_t)(s0 + s1 + s2 + s3);
   uint32_t T = r.thr_T;
   bool none = false;
-  if (sum >= r.thr_below) T = child_threshold(sum, r.ratio, r.n_cutoff, &none);
+  if (sum >= r.thr_below) T = threshold_of((double)(uint32_t)sum * r.ratio, r.nc, &none);   // (four 16-bit counts)
   uint32_t m4 = (s0 >= T ? 1u : 0u) | (s1 >= T ? 2u : 0u) | (s2 >= T ? 4u : 0u) | (s3 >= T ? 8u : 0u);
   if (none) m4 = 0;
   const bool single = !esc && m4 != 0 && (m4 & (m4 - 1)) == 0;

@@ -153,6 +153,8 @@ static TableView view_of(const kmjf* h) {
   t.kmask = mask_bits(h->k);
   t.pmask = mask_bits(h->k - 1);
   t.n_buckets = h->n_buckets;
+  t.bshift = 31;                                    // (n_buckets: a power of two, 2^4 .. 2^30; 0 before the build)
+  while (t.bshift > 1 && (1ull << (32 - t.bshift)) < h->n_buckets) --t.bshift;
   t.unit = h->unit;
   t.max_probe = h->max_probe;
   t.k = h->k;
@@ -1083,6 +1085,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.n_targets = b->n_targets;
   a.ratio = b->p.ratio;
   a.n_cutoff = b->p.count;
+  a.nc = (double)b->p.count;
   threshold_shortcut(a.ratio, a.n_cutoff, &a.thr_below, &a.thr_T);
   a.max_stack = b->p.max_stack;
   a.max_break = b->p.max_break;

@@ -97,6 +97,7 @@ struct WalkArgs {
   uint32_t n_targets;
   double ratio;
   int64_t n_cutoff;
+  double nc;                       // (double)n_cutoff: the kernels compare against it (device_common.h: child_mask)
   uint64_t thr_below;         // sums < thr_below have the threshold thr_T (device_common.h: threshold_shortcut)
   uint32_t thr_T;
   uint32_t max_stack, max_break, max_node;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
       a.node_cnt[nb] = v;
     }
     if (a.max_stack > 0) {
-      const uint32_t mask = child_mask(c4, a.ratio, a.n_cutoff);
+      const uint32_t mask = child_mask(c4, a.ratio, a.nc);
       triv = (mask == 0) || (nextb < 4 && mask == (1u << nextb));
       triv_child = triv && mask != 0;
       if (!triv) {
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   bl.valid = false; bl.resident = false; bl.bucket = 0; bl.S = 0;
 #pragma unroll
   for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) { bl.tag[i] = EMPTY; bl.ntag[i] = EMPTY; bl.info[i] = 0; }
-  const ChildRule rule = {a.ratio, a.n_cutoff, a.thr_below, a.thr_T};
+  const ChildRule rule = {a.ratio, a.nc, a.thr_below, a.thr_T};
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             KM_DFS_STAMP(2);                               // wait for the pair + resolve
             pend.valid = false;
             probes_u += 4;
-            mask = child_mask(c4, a.ratio, a.n_cutoff);
+            mask = child_mask(c4, a.ratio, a.nc);
             brk = parent_brk;
             if (__popc(mask) > 1) {
               ++brk;
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 // themselves are not kept in the lanes
                 c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
               }
-              const uint32_t xm = child_mask(c4, a.ratio, a.n_cutoff);
+              const uint32_t xm = child_mask(c4, a.ratio, a.nc);
               KM_DFS_STAMP(13);                            // chain: full expansion
               if (xm != 0 && (xm & (xm - 1)) == 0) {
                 c = (uint32_t)__ffs((int)xm) - 1;
