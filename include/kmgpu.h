@@ -85,7 +85,7 @@ typedef struct {
   uint64_t n_nodes;        /* over all targets, caps excluded                  */
   uint64_t n_runs;         /* path run-length records over all paths           */
   uint64_t logical_probes; /* reference-semantics Jellyfish.query calls        */
-  uint64_t table_fetches;  /* 16-byte table slots actually read by the walk    */
+  uint64_t table_fetches;  /* 16-byte table slots actually read by the walk (KM_RUN_COUNT_FETCHES; else 0) */
   uint32_t n_big_tier;     /* targets that needed the large-workspace pass     */
   uint32_t n_flagged;      /* targets with at least one non-trivial seed       */
   uint64_t seed_probes;    /* logical probes answered by the k_seed kernel     */
@@ -220,6 +220,9 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
  * (km_batch_out_t.node_count16 / count_esc_*; at most 2048 of those per delivery, else the library quietly
  * delivers the 32-bit form).  km_report_rows reads either form; km_batch_fetch always fills 32-bit counts. */
 #define KM_DELIVER_COUNT16 128
+/* Count the 16-byte table slots the walk reads (km_batch_sizes_t.table_fetches; 0 without this flag): a
+ * diagnostic — two ballots and one more atomic per wave of k_seed, 2 % of a pipelined step. */
+#define KM_RUN_COUNT_FETCHES 256
 /* Record the HIP events km_batch_timings reads (seven event records per run; off by default). */
 #define KM_RUN_TIMED 32
 /* Kept for callers of round 2: a batch's kernels now ALWAYS run in `stream`, in order (the pass over the

@@ -58,6 +58,7 @@ struct OutArgs {
   uint32_t ran_graph;
   uint32_t lean;                       // omit the node counts of bare-reference targets
   uint32_t count16;                    // node counts as 16-bit values + escape list
+  uint32_t count_fetches;              // the run counted table slots read (KM_RUN_COUNT_FETCHES); else reported as 0
   unsigned long long serial;           // stamped into totals[OT_SERIAL]: which run this delivery belongs to
   // walk / graph results
   const uint32_t* status;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(OUT_SCAN_THREADS) void k_out_scan(OutArgs a) {
     const OutCounts c = out_counts_of(a, t, &needs, &st);
     s[0] = c.nodes; s[1] = c.extra; s[2] = c.paths; s[3] = c.runs;
     const unsigned long long sp = a.probes[t], dp = a.dfs_probes[t];
-    seedp = sp; probes = sp + dp; fetches = a.fetches[t];
+    seedp = sp; probes = sp + dp; fetches = a.count_fetches ? a.fetches[t] : 0ull;
     a.o_status[t] = st;
     a.o_nref[t] = a.n_ref[t];
     a.o_probes[t] = sp + dp;

@@ -816,6 +816,7 @@ struct km_batch {
   bool deliver_pending = false, result_ready = false;
   bool lean = false;                  // the pending / ready delivery omits bare-reference node counts
   bool count16 = false;               // ... and carries 16-bit counts + escape list (KM_DELIVER_COUNT16)
+  bool count_fetches = false;         // the last run counted table slots read (KM_RUN_COUNT_FETCHES)
   uint64_t copied_tail = 0, tail_guess = 0;
   unsigned long long serial = 0;
   std::vector<uint64_t> h_packed;     // km_batch_fetch: packed targets, when node_kmer is asked for
@@ -1263,10 +1264,15 @@ static int launch_graph_fast(km_batch* b, hipStream_t st) {
   return KM_OK;
 }
 
-static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa) {
-  if (wa.stamps) hipLaunchKernelGGL((k_seed<true, 0>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);   // KM_SEED_STAMPS diagnostics
-  else if (wa.tab.k == 31) hipLaunchKernelGGL((k_seed<false, 31>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
-  else hipLaunchKernelGGL((k_seed<false, 0>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+static void launch_seed(uint32_t n_items, hipStream_t st, const WalkArgs& wa, bool count_fetches) {
+  if (wa.stamps) hipLaunchKernelGGL((k_seed<true, 0, true>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);   // KM_SEED_STAMPS diagnostics
+  else if (wa.tab.k == 31) {
+    if (count_fetches) hipLaunchKernelGGL((k_seed<false, 31, true>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+    else hipLaunchKernelGGL((k_seed<false, 31, false>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+  } else {
+    if (count_fetches) hipLaunchKernelGGL((k_seed<false, 0, true>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+    else hipLaunchKernelGGL((k_seed<false, 0, false>), dim3(n_items), dim3(SEED_BLOCK), 0, st, wa);
+  }
 }
 
 // Compaction kernels + ONE asynchronous copy of region A and the expected part of the tail into
@@ -1293,6 +1299,7 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean, bool count16 
   oa.ran_graph = (b->ran_graph && b->graph_mode == 0) ? 1u : 0u;
   oa.lean = lean ? 1u : 0u;
   oa.count16 = count16 ? 1u : 0u;
+  oa.count_fetches = b->count_fetches ? 1u : 0u;
   oa.serial = ++b->serial;
   oa.status = b->d_status.p; oa.g_status = b->d_gstatus.p; oa.n_nodes = b->d_n_nodes.p; oa.n_ref = b->d_n_ref.p;
   oa.t_npaths = b->d_npaths.p; oa.t_pathbase = b->d_pathbase.p; oa.t_nruns = b->d_t_nruns.p;
@@ -1379,6 +1386,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   const bool want_deliver = (stages & KM_RUN_DELIVER) != 0;
   const bool want_lean = (stages & KM_DELIVER_LEAN) != 0;
   const bool want_c16 = (stages & KM_DELIVER_COUNT16) != 0;
+  if (stages & KM_STAGE_WALK) b->count_fetches = (stages & KM_RUN_COUNT_FETCHES) != 0;
   const bool want_timed = (stages & KM_RUN_TIMED) != 0;
   const bool serial = (stages & KM_RUN_SERIAL) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
@@ -1440,7 +1448,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     hipLaunchKernelGGL(k_pack, dim3((b->n_targets + PACK_WAVES - 1) / PACK_WAVES), dim3(64 * PACK_WAVES), 0, st, wa);
     if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
-      launch_seed(b->n_items, st, wa);
+      launch_seed(b->n_items, st, wa, b->count_fetches);
     if (b->timed) HIPCHK(hipEventRecord(b->ev[4], st));
     // a batch's kernels run in ONE stream, in order (k_graph_pure after k_dfs): batches overlap with each
     // other, every launch stream on a hardware queue of its own (see "streams" above).  (Round 2 ran

@@ -352,7 +352,9 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
 //    (one LDS round trip: w/2 ds_read2 + w/2 v_min3);
 //  * the lookup is key -> directory word -> the aligned home pair, three dependent loads with
 //    no loop (device_common.h: the build guarantees the pair).
-template <bool STAMPS, int K>
+// FETCHES: count the table slots read per target (km_batch_sizes_t.table_fetches; KM_RUN_COUNT_FETCHES) — two
+// ballots and one more atomic per wave, 2 % of the pipelined step, so only on request
+template <bool STAMPS, int K, bool FETCHES>
 __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   static_assert(SEED_BLOCK == 256, "the item record holds 12 words = 256 seeds + k - 1 + 1 bases");
   constexpr uint32_t RAW = SEED_BLOCK + 32;                // selection keys of the item's m-mers
@@ -493,15 +495,18 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
   // a table whose build gave up the pair bound.
   const unsigned long long probes_w = (unsigned long long)__popcll(__ballot(valid)) +
                                       4ull * __popcll(__ballot(triv)) + __popcll(__ballot(triv_child));
-  unsigned long long fetch_w = (unsigned long long)__popcll(__ballot(fetch_l >= 1)) + __popcll(__ballot(fetch_l >= 2));
-  if (__any(fetch_l > 2)) {
-    uint32_t extra = fetch_l > 2 ? fetch_l - 2 : 0;
-    for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o);
-    fetch_w += extra;
+  unsigned long long fetch_w = 0;
+  if constexpr (FETCHES || STAMPS) {
+    fetch_w = (unsigned long long)__popcll(__ballot(fetch_l >= 1)) + __popcll(__ballot(fetch_l >= 2));
+    if (__any(fetch_l > 2)) {
+      uint32_t extra = fetch_l > 2 ? fetch_l - 2 : 0;
+      for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o);
+      fetch_w += extra;
+    }
   }
   if (lane == 0 && probes_w) {
     atomicAdd(&a.probes[t], probes_w);
-    atomicAdd(&a.fetches[t], fetch_w);
+    if constexpr (FETCHES || STAMPS) atomicAdd(&a.fetches[t], fetch_w);
   }
   if constexpr (STAMPS) {
     KM_SEED_STAMP(7);

@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("KM_LIBRARY") or os.path.join(_HERE, "libkmgpu.so")
 KM_OK = 0
 KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER, KM_DELIVER_LEAN, KM_RUN_TIMED = 1, 2, 4, 8, 16, 32
 KM_DELIVER_COUNT16 = 128        # node counts cross PCIe as 16-bit values + the list of the exact counts >= 65535
+KM_RUN_COUNT_FETCHES = 256      # count the table slots read (sizes.table_fetches; a diagnostic, 2 % of a step)
 KM_RUN_SERIAL = 64
 T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 

@@ -852,6 +852,27 @@ def test_sixteen_bit_counts_deliver_the_same_results():
         db.close()
 
 
+def test_table_fetches_are_counted_on_request_only():
+    """KM_RUN_COUNT_FETCHES: sizes.table_fetches counts the 16-byte slots the walk read — a diagnostic that costs
+    k_seed two ballots and an atomic per wave, so it is 0 unless asked for; the results do not depend on it."""
+    case = synth.make_case(n_targets=400, length=300, n_keys=100_000, seed=41, variant_frac=0.4)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31).upload(0)
+    b = kmlib.Batch(db, max_targets=400, max_total_bases=400 * 300)
+    b.set_targets([km.decode(r) for r in case["targets"]])
+    flags = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
+    b.run(flags)
+    r0, s0 = b.fetch(), b.sizes()
+    b.run(flags | kmlib.KM_RUN_COUNT_FETCHES)
+    r1, s1 = b.fetch(), b.sizes()
+    assert int(s0.table_fetches) == 0 and int(s1.table_fetches) >= int(s1.n_nodes) // 2
+    assert int(s0.logical_probes) == int(s1.logical_probes) > 0
+    for key in r0:
+        if key != "table_fetches":
+            assert np.array_equal(r0[key], r1[key]), key
+    b.close()
+    db.close()
+
+
 def test_serial_measurement_flag_changes_nothing():
     """KM_RUN_SERIAL only moves k_graph_pure from the side stream behind k_dfs."""
     case = synth.make_case(n_targets=300, length=300, n_keys=60_000, seed=99, variant_frac=0.4)
