@@ -261,12 +261,19 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
   // ---- global offsets: sizes of the scan blocks before this target's + the batch totals
   // (prefix sums by the last block of k_out_scan)
   const uint32_t nblk = (n + OUT_SCAN_THREADS - 1) / OUT_SCAN_THREADS, myblk = t / OUT_SCAN_THREADS;
+  // every word that depends on the target alone is requested here, with the block bases (they used to follow
+  // one another behind the offsets: five dependent round trips per wave, most of a wave's 3.5 us)
+  const ulonglong4 lc = reinterpret_cast<const ulonglong4*>(a.loc)[t];
+  const uint4 ct = reinterpret_cast<const uint4*>(a.cnt)[t];
+  const uint64_t nb = a.node_base[t];
+  const uint32_t pb = a.t_pathbase[t];
+  const unsigned long long pool_ovf = a.ran_graph ? *a.pool_overflow : 0ull;
   unsigned long long pre[4], tot[8];
   {
-    const ulonglong4 pb = *reinterpret_cast<const ulonglong4*>(a.blk_base + 4ull * myblk);
+    const ulonglong4 bb = *reinterpret_cast<const ulonglong4*>(a.blk_base + 4ull * myblk);
     const ulonglong4* G = reinterpret_cast<const ulonglong4*>(a.blk_base + 4ull * nblk);
     const ulonglong4 g0 = G[0], g1 = G[1];
-    pre[0] = pb.x; pre[1] = pb.y; pre[2] = pb.z; pre[3] = pb.w;
+    pre[0] = bb.x; pre[1] = bb.y; pre[2] = bb.z; pre[3] = bb.w;
     tot[0] = g0.x; tot[1] = g0.y; tot[2] = g0.z; tot[3] = g0.w;
     tot[4] = g1.x; tot[5] = g1.y; tot[6] = g1.z; tot[7] = g1.w;
   }
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
   const uint64_t off_rstart = o; o = out_align(o + 4 * tot[3]);
   const uint64_t off_rlen = o;   o = out_align(o + 4 * tot[3]);
   unsigned long long nh = tot[7];
-  if (a.ran_graph && *a.pool_overflow) nh |= 1ull;
+  if (pool_ovf) nh |= 1ull;
   if (tot[2] >= (1ull << 32)) nh |= 1ull;            // path_off is 32-bit: the host splits such batches
   if (o > a.tail_cap) nh |= 2ull;
   if (t == 0 && lane == 0) {
@@ -295,14 +302,11 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
     a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
   }
   if (nh) return;                        // the host finishes the batch and delivers again
-  const ulonglong4 lc = reinterpret_cast<const ulonglong4*>(a.loc)[t];
-  const uint4 ct = reinterpret_cast<const uint4*>(a.cnt)[t];
   const uint64_t n0 = pre[0] + lc.x, e0 = pre[1] + lc.y;
   const uint32_t p0 = (uint32_t)(pre[2] + lc.z);
   uint64_t cur = pre[3] + lc.w;          // first output run of this target
   const uint32_t nn = ct.x, ne = ct.y, np = ct.z;
   if (lane == 0) { a.o_node_off[t] = n0; a.o_extra_off[t] = e0; a.o_path_off[t] = p0; }
-  const uint64_t nb = a.node_base[t];
   uint32_t* o_cnt = reinterpret_cast<uint32_t*>(a.tail + off_count);
   uint64_t* o_ext = reinterpret_cast<uint64_t*>(a.tail + off_extra);
   uint32_t* o_plen = reinterpret_cast<uint32_t*>(a.tail + off_plen);
@@ -348,7 +352,6 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
   if (t + 1 == n && lane == 0) o_roff[tot[2]] = tot[3];
   // ---- paths, sorted by index sequence
   if (np == 0) return;
-  const uint32_t pb = a.t_pathbase[t];
   if (np == 1) {
     const uint32_t nr = a.p_nruns[pb];
     const uint64_t rb = a.p_runbase[pb];

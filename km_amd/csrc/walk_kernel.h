@@ -250,9 +250,14 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
   const uint32_t t = blockIdx.x * PACK_WAVES + (threadIdx.x >> 6);
   const uint32_t lane = (uint32_t)lane_id();
   if (t >= a.n_targets) return;          // whole waves only; nothing below synchronises across waves
+  // every per-target header word is requested here, together (three of them used to be loaded behind the packing
+  // loop and behind its fences: four dependent round trips per wave instead of two)
   const uint64_t off = a.toff[t];
   const uint64_t L = a.toff[t + 1] - off;
   const uint64_t wo = a.woff[t];
+  const uint64_t fwo = a.fw_off[t];
+  const uint64_t nbase = a.node_base[t];
+  const uint64_t item0 = a.item_off[t];
   const uint32_t nwords = (uint32_t)((L + 31) >> 5);
   const uint32_t n_ref = (L >= (uint64_t)a.tab.k) ? (uint32_t)(L - a.tab.k + 1) : 0;
   uint32_t bad = 0;
@@ -262,11 +267,19 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
   for (uint32_t c = 0; c * 8 <= nwords; ++c) {
     const uint64_t p = (uint64_t)c * 256 + lane * 4;
     uint32_t byte = 0;
+    uint32_t four = 0;                       // the lane's four characters, first one in the low byte
+    if (p + 4 <= L) {
+      __builtin_memcpy(&four, a.bases + off + p, 4);           // (one load; global memory takes it unaligned)
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (p + j < L) four |= (uint32_t)a.bases[off + p + j] << (8 * j);
+    }
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
       uint32_t code = 0;
       if (p + j < L) {
-        const uint32_t ch = a.bases[off + p + j] & 0xDFu;       // upper-case
+        const uint32_t ch = (four >> (8 * j)) & 0xDFu;          // upper-case
         bad |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
         code = ((ch >> 1) ^ (ch >> 2)) & 3u;
       }
@@ -283,7 +296,6 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
     }
   }
   const bool in_lds = nwords < PACK_LDS_WORDS;
-  const uint64_t fwo = a.fw_off[t];
   for (uint32_t w = lane; w < (n_ref + 31) / 32; w += 64) a.flagbits[fwo + w] = 0;
   const int any_bad = __any((int)bad);
   uint32_t st = T_OK;
@@ -300,8 +312,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
   }
   {
     const uint32_t n_it = (n_ref + SEED_BLOCK - 1) / SEED_BLOCK;
-    const uint64_t nbase = a.node_base[t];
-    uint64_t* rec0 = a.items + 16ull * a.item_off[t];
+    uint64_t* rec0 = a.items + 16ull * item0;
     for (uint32_t x = lane; x < n_it * 16; x += 64) {
       const uint32_t q = x >> 4, f = x & 15;
       uint64_t v;
