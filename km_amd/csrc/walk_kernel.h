@@ -1152,7 +1152,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   //  (R4) or a reference node b, which ends the bubble (the next walk node, if any, heads the next): b > a
   //       with (b - a) x 0.01 well below the bubble's cost, or b <= a (a tandem duplication: the
   //       bubble leads back; both shortest-path trees stay on the reference chain then as well),
-  // the paths are the reference path and, per bubble, 0..a, the bubble, b..n_ref-1.  The node set of the
+  // the paths are the reference path and, per bubble, 0..a, the bubble, b..n_ref-1 (and, for a bubble whose last
+  // node points at its own head beside b = a + 1 — a loop — the same with the bubble twice).  The node set of the
   // walk answers "which node is this k-mer" (state NODE + index per slot), and "who has prefix P" is
   // the four k-mers P+A, P+C, P+G, P+T: no prefix table, no adjacency, no Dijkstra.  Everything else
   // (loops, dead ends, nested bubbles, a bubble cheaper than the reference route, more than
@@ -1169,14 +1170,18 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
       constexpr uint32_t REF_REGS = 8;                     // reference counts a lane keeps (targets of up to 512 k-mers)
       // the nodes whose k-mer has the (k-1)-mer prefix P, the node `self` aside: how many, and one of
       // them.  They all sit in the probe sequence that starts at P's home slot.
-      auto nodes_with_prefix = [&](uint64_t P, uint32_t self, uint32_t* one) -> uint32_t {
+      auto nodes_with_prefix = [&](uint64_t P, uint32_t self, uint32_t* one, uint32_t* first = nullptr) -> uint32_t {
         uint32_t cnt = 0, sl = set_home(P, cap);
         for (uint32_t step = 0; step < cap; ++step) {
           const uint64_t kv = keys[sl];
           if (kv == EMPTY) break;
           if ((kv >> 2) == P) {
             const uint16_t mv = state[sl];
-            if (meta_state(mv) == ST_NODE && meta_index(mv) != self) { ++cnt; *one = meta_index(mv); }
+            if (meta_state(mv) == ST_NODE && meta_index(mv) != self) {
+              if (cnt == 0 && first) *first = meta_index(mv);
+              ++cnt;
+              *one = meta_index(mv);                       // (the last one found)
+            }
           }
           if (++sl == cap) sl = 0;
         }
@@ -1203,14 +1208,14 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
       }
       uint32_t bad = 0;
       const uint64_t last_suffix = kmer_at(n_ref - 1) & tab.pmask;    // (R1): no walk node behind it either
-      uint32_t w_a[EPI_CHUNKS], w_nx[EPI_CHUNKS];
+      uint32_t w_a[EPI_CHUNKS], w_nx[EPI_CHUNKS], w_lp[EPI_CHUNKS];
       unsigned long long Hm[EPI_CHUNKS], Em[EPI_CHUNKS];
       // pass 1 — who shares a walk node's prefix: at most one node, a reference node x >= 1 (R2)
 #pragma unroll
       for (uint32_t q = 0; q < EPI_CHUNKS; ++q) {
         const uint32_t e = n_ref + 64u * q + lane;
         bool head = false;
-        w_a[q] = 0; w_nx[q] = NONE;
+        w_a[q] = 0; w_nx[q] = NONE; w_lp[q] = NONE;
         if (64u * q < n_walk) {                            // wave-uniform
           if (e < m) {
             const uint64_t X = w_x[q];
@@ -1246,9 +1251,19 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           const uint64_t S = X & tab.pmask;
           const bool chained = e + 1 < m && (Xn >> 2) == S && !next_head;
           if (e < m && !chained) {
-            uint32_t nx = NONE;
-            const uint32_t sc = nodes_with_prefix(S, NONE, &nx);
-            if (sc != 1 || nx >= n_ref) bad = 1;            // (a walk node behind it that is not e + 1, or e + 1 a head as well)
+            uint32_t nx = NONE, n1 = NONE;
+            const uint32_t sc = nodes_with_prefix(S, NONE, &nx, &n1);
+            if (sc == 2) {
+              // two nodes behind the end of a bubble: a reference node b and a walk node — the bubble's OWN head,
+              // if this is a loop (a tandem duplication a little shorter than k: the head shares its prefix with
+              // b = a + 1, so whatever points at b points at the head as well; checked below, where the head is
+              // known).  One more path then: through the bubble twice (tests/test_bubble_theory.py).
+              const uint32_t lo = n1 < nx ? n1 : nx, hi = n1 < nx ? nx : n1;
+              if (lo < n_ref && hi >= n_ref) { nx = lo; w_lp[q] = hi; }
+              else bad = 1;
+            } else if (sc != 1 || nx >= n_ref) {
+              bad = 1;                                     // (a walk node behind it that is not e + 1, or e + 1 a head as well)
+            }
             is_end = true;
             w_nx[q] = nx;
           }
@@ -1273,6 +1288,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
       // per bubble (at its end node): a from its head, b, and — for a forward bubble — the margin that
       // keeps both shortest-path trees on the reference edges
       uint32_t my_a = 0, my_s = 0, my_e = 0, my_b = 0;     // lane r: bubble r (in node order)
+      bool my_loop = false;                                // ... and whether it leads back to its own head as well
       if (!__any((int)bad) && n_bub <= EPI_MAX_BUBBLES) {
         uint32_t rank_base = 0;
 #pragma unroll
@@ -1298,13 +1314,15 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             const uint32_t s_node = n_ref + hpos, b_node = w_nx[q];
             if (hpos == NONE || b_node > n_ref - 1 ||
                 (a_here < b_node && (uint64_t)(b_node - a_here) + 10 > 100ull * (e - s_node + 2))) bad = 1;
+            if (w_lp[q] != NONE && (w_lp[q] != s_node || b_node != a_here + 1)) bad = 1;   // not this bubble's own loop
           }
           // hand bubble r to lane r
           for (unsigned long long em = Em[q]; em; em &= em - 1) {
             const uint32_t l = (uint32_t)__ffsll((long long)em) - 1;
             const uint32_t r = rank_base + (uint32_t)__popcll(Em[q] & ((1ull << l) - 1ull));
             const uint32_t va = lane_u32(a_here, l), vs = lane_u32(hpos, l), vb = lane_u32(w_nx[q], l);
-            if (lane == r) { my_a = va; my_s = n_ref + vs; my_e = n_ref + 64u * q + l; my_b = vb; }
+            const uint32_t vl = lane_u32(w_lp[q], l);
+            if (lane == r) { my_a = va; my_s = n_ref + vs; my_e = n_ref + 64u * q + l; my_b = vb; my_loop = vl != NONE; }
           }
           rank_base += (uint32_t)__popcll(Em[q]);
         }
@@ -1314,11 +1332,15 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         // now; the answer is needed only after the coverages are known
         const uint32_t pg = t % POOL_GROUPS;
         const uint64_t pg_paths = ea.path_pool / POOL_GROUPS, pg_runs = ea.run_pool / POOL_GROUPS;
+        // (a looped bubble has two paths: once and twice through it — three and four runs)
+        const unsigned long long loops = __ballot(lane < n_bub && my_loop);
+        const uint32_t n_loop = (uint32_t)__popcll(loops);
+        const unsigned long long want_paths = 1ull + n_bub + n_loop, want_runs = 1ull + 3ull * n_bub + 4ull * n_loop;
         unsigned long long pb = 0, rb = 0;
         if (lane == 0) {
           unsigned long long* ctr = ea.counters + (uint64_t)pg * POOL_CTR_STRIDE;
-          pb = atomicAdd(&ctr[0], 1ull + n_bub);
-          rb = atomicAdd(&ctr[1], 1ull + 3ull * n_bub);
+          pb = atomicAdd(&ctr[0], want_paths);
+          rb = atomicAdd(&ctr[1], want_runs);
         }
         uint32_t ref_min = 0xFFFFFFFFu, ref_max = 0;
 #pragma unroll
@@ -1356,7 +1378,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         }
         pb = lane_u64(pb, 0);
         rb = lane_u64(rb, 0);
-        if (pb + 1 + n_bub > pg_paths || rb + 1 + 3ull * n_bub > pg_runs) {
+        if (pb + want_paths > pg_paths || rb + want_runs > pg_runs) {
           // pools exhausted: the host enlarges them and reruns the graph stage over every flagged target
           if (lane == 0) {
             atomicExch(ea.counters + (uint64_t)POOL_GROUPS * POOL_CTR_STRIDE, 1ull);
@@ -1368,7 +1390,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           if (lane == 0) {
             ea.r_start[rb] = 0; ea.r_len[rb] = n_ref;
             ea.p_target[pb] = t; ea.p_runbase[pb] = rb; ea.p_nruns[pb] = 1; ea.p_len[pb] = n_ref; ea.p_mincov[pb] = ref_min;
-            ea.t_npaths[t] = 1 + n_bub; ea.t_pathbase[t] = (uint32_t)pb; ea.t_nruns[t] = 1 + 3 * n_bub;
+            ea.t_npaths[t] = (uint32_t)want_paths; ea.t_pathbase[t] = (uint32_t)pb; ea.t_nruns[t] = (uint32_t)want_runs;
             ea.t_refmax[t] = n_bub ? NOT_BARE : ref_max;
             ea.g_status[t] = T_OK;
           }
@@ -1379,6 +1401,16 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             ea.r_start[r0 + 2] = my_b; ea.r_len[r0 + 2] = n_ref - my_b;
             ea.p_target[p0] = t; ea.p_runbase[p0] = r0; ea.p_nruns[p0] = 3;
             ea.p_len[p0] = (my_a + 1) + (my_e - my_s + 1) + (n_ref - my_b); ea.p_mincov[p0] = my_mc;
+            if (my_loop) {                                 // 0..a, the bubble twice, b..n_ref-1: the same nodes, the same coverage
+              const uint32_t lr = (uint32_t)__popcll(loops & ((1ull << lane) - 1ull));
+              const uint64_t r1 = rb + 1 + 3ull * n_bub + 4ull * lr, p1 = pb + 1 + n_bub + lr;
+              ea.r_start[r1] = 0; ea.r_len[r1] = my_a + 1;
+              ea.r_start[r1 + 1] = my_s; ea.r_len[r1 + 1] = my_e - my_s + 1;
+              ea.r_start[r1 + 2] = my_s; ea.r_len[r1 + 2] = my_e - my_s + 1;
+              ea.r_start[r1 + 3] = my_b; ea.r_len[r1 + 3] = n_ref - my_b;
+              ea.p_target[p1] = t; ea.p_runbase[p1] = r1; ea.p_nruns[p1] = 4;
+              ea.p_len[p1] = (my_a + 1) + 2 * (my_e - my_s + 1) + (n_ref - my_b); ea.p_mincov[p1] = my_mc;
+            }
           }
         }
         answered = true;

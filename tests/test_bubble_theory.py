@@ -97,11 +97,13 @@ def test_closed_form_equals_the_reference_algorithm(k):
     assert n_shape >= 10 and n_other >= 10, (n_shape, n_other)       # both sides of the conditions were met
 
 
-def bubbles_shape(kmers, n_ref, allow_back=False):
+def bubbles_shape(kmers, n_ref, allow_back=False, allow_loop=False):
     """The shape the epilogue of k_dfs answers (walk_kernel.h): the reference chain plus ANY number of
     bubbles, each a run of consecutive walk nodes s..e hanging off reference node a and leading back to
     reference node b — forward (b > a, with the cost margin) or, with allow_back, backward (b <= a: a
-    tandem duplication).  Returns [(a, s, e, b)] or None."""
+    tandem duplication).  Returns [(a, s, e, b)] or None.  With allow_loop a bubble may also lead back to
+    ITS OWN head beside b (a tandem duplication a little shorter than k: the head shares its prefix with b =
+    a + 1, so whatever points at b points at the head too): tuples are then (a, s, e, b, looped)."""
     m = len(kmers)
     if not (m > n_ref >= 2):
         return None
@@ -128,8 +130,12 @@ def bubbles_shape(kmers, n_ref, allow_back=False):
         if e not in head_of:
             return None                                 # a chain must start at a head
         a, s = head_of[e], e
+        looped = False
         while True:
             behind = by_prefix.get(kmers[e][1:], [])
+            if allow_loop and len(behind) == 2 and s in behind and min(behind) == a + 1:
+                b, looped = a + 1, True                 # the end of the bubble points at b and at its own head
+                break
             if len(behind) != 1:
                 return None
             nxt = behind[0]
@@ -146,7 +152,7 @@ def bubbles_shape(kmers, n_ref, allow_back=False):
                 return None
         elif not allow_back:
             return None
-        bubbles.append((a, s, e, b))
+        bubbles.append((a, s, e, b, looped) if allow_loop else (a, s, e, b))
         e += 1
     return bubbles
 
@@ -219,3 +225,70 @@ def test_closed_form_with_backward_bubbles(k):
             got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
             assert got == want, (k, trial, name, shape, n_ref, len(kmers))
     assert n_back >= 10 and n_mixed >= 10, (n_back, n_mixed)
+
+
+def _tandem_case(rng, k):
+    """A random target with a tandem duplication of k-4 .. k-1 bases (and sometimes an SNV elsewhere) in a
+    database of its own: (sequence, KmerDB)."""
+    while True:
+        L = int(rng.integers(6 * k, 12 * k))
+        row = rng.integers(0, 4, size=L, dtype=np.uint8)
+        refk = km.sliding_kmers(row[None, :], k)[0]
+        if len(set(refk.tolist())) != len(refk):
+            continue
+        n = int(rng.integers(k - 4, k))
+        p = int(rng.integers(k, L - k - n))
+        muts = [np.concatenate([row[:p + n], row[p:p + n], row[p + n:]]).astype(np.uint8)]
+        if rng.random() < 0.5:                                    # a second, ordinary variant well away from it
+            q = int(rng.integers(k, L - k))
+            if abs(q - p) > 3 * k:
+                snv = row.copy()
+                snv[q] = (snv[q] + 1 + rng.integers(0, 3)) % 4
+                muts.append(snv)
+        counts = {}
+        refset = set(refk.tolist())
+        for x in refk.tolist():
+            counts[km.canonical(x, k)] = 100
+        for mut in muts:
+            for x in km.sliding_kmers(mut[None, :], k)[0].tolist():
+                if x not in refset:
+                    counts[km.canonical(x, k)] = 60
+        keys = np.array(sorted(counts), dtype=np.uint64)
+        vals = np.array([counts[x] for x in sorted(counts)], dtype=np.uint32)
+        return km.decode(row), ko.KmerDB(None, cutoff=0.05, n_cutoff=5,
+                                         records={"k": k, "canonical": True, "keys": keys, "counts": vals})
+
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+def test_closed_form_with_looped_bubbles(k):
+    """A tandem duplication a little shorter than k: the bubble's head shares its prefix with b = a + 1, so the
+    bubble's last node points at b AND at the head — a loop.  The reference's algorithm then finds one more
+    path, through the loop edge: 0..a, the bubble TWICE, b..n_ref-1 (shortest source -> end of the bubble, the
+    loop edge, shortest head -> sink); everything else is as for an ordinary forward bubble with b - a = 1.
+    All 13 targets of the bench batch that round 3's epilogue still left to k_graph are of this kind."""
+    rng = np.random.default_rng(77000 + k)
+    n_loop = n_loop_mixed = 0
+    for trial in range(260):
+        seq, db = _tandem_case(rng, k)
+        try:
+            mers = ko.ref_kmers(seq, "t", k)
+            nodes = ko.walk(mers, db)
+        except (ValueError, ko.NodeLimit):
+            continue
+        kmers = list(nodes.keys())
+        n_ref = len(mers)
+        shape = bubbles_shape(kmers, n_ref, allow_back=True, allow_loop=True)
+        if shape is None:
+            continue
+        loops = sum(1 for x in shape if x[4])
+        n_loop += loops > 0
+        n_loop_mixed += loops > 0 and len(shape) > loops
+        want = [tuple(range(n_ref))]
+        for a, s, e, b, looped in shape:
+            once = tuple(range(a + 1)) + tuple(range(s, e + 1)) + tuple(range(b, n_ref))
+            want.append(once)
+            if looped:
+                want.append(tuple(range(a + 1)) + 2 * tuple(range(s, e + 1)) + tuple(range(b, n_ref)))
+        got = [tuple(p) for p in ko.graph_paths(kmers, n_ref)]
+        assert got == sorted(want), (k, trial, shape, n_ref, len(kmers))
+    assert n_loop >= 15 and n_loop_mixed >= 3, (n_loop, n_loop_mixed)

@@ -852,6 +852,63 @@ def test_sixteen_bit_counts_deliver_the_same_results():
         db.close()
 
 
+@pytest.mark.parametrize("k", [21, 31])
+def test_epilogue_answers_looped_bubbles(k):
+    """A tandem duplication of k-4 .. k-1 bases: the bubble's last node points at the reference node behind the
+    bubble's entry AND at the bubble's own head; the reference finds the path through the bubble once and the one
+    through it twice (tests/test_bubble_theory.py::test_closed_form_with_looped_bubbles).  The epilogue of k_dfs
+    writes both (the 13 targets of the bench batch it used to leave to k_graph are of this kind): every target
+    against the oracle, nothing left to k_graph, paths of four runs among the results."""
+    rng = np.random.default_rng(8800 + k)
+    rows, counts = [], {}
+    n_t, L = 240, 12 * k
+    while len(rows) < n_t:
+        row = rng.integers(0, 4, size=L, dtype=np.uint8)
+        refk = km.sliding_kmers(row[None, :], k)[0]
+        if len(set(refk.tolist())) != len(refk):
+            continue
+        n = int(rng.integers(k - 4, k))
+        p = int(rng.integers(k, L - k - n))
+        muts = [np.concatenate([row[:p + n], row[p:p + n], row[p + n:]]).astype(np.uint8)]
+        q = int(rng.integers(k, L - k))
+        if len(rows) % 2 and abs(q - p) > 3 * k:                  # every other target: an SNV elsewhere as well
+            snv = row.copy()
+            snv[q] = (snv[q] + 1 + rng.integers(0, 3)) % 4
+            muts.append(snv)
+        refset = set(refk.tolist())
+        cov = int(rng.integers(80, 900))
+        for x in refk.tolist():
+            counts[jr.canonical(x, k)] = cov
+        for mut in muts:
+            for x in km.sliding_kmers(mut[None, :], k)[0].tolist():
+                if x not in refset:
+                    counts[jr.canonical(x, k)] = max(6, int(cov * 0.4))
+        rows.append(row)
+    keys = np.array(sorted(counts), dtype=np.uint64)
+    vals = np.array([counts[x] for x in sorted(counts)], dtype=np.uint32)
+    db = kmlib.Database.from_records(keys, vals, k).upload(0)
+    seqs = [km.decode(r) for r in rows]
+    b = kmlib.Batch(db, max_targets=n_t, max_total_bases=n_t * L)
+    b.set_targets(seqs)
+    b.run()
+    res = b.fetch()
+    flagged, _handed, left = b.debug_counts()
+    assert flagged == n_t and left <= n_t // 20, (flagged, left)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": k, "canonical": True, "keys": keys, "counts": vals})
+    noff, poff = res["node_off"].astype(np.int64), res["path_off"].astype(np.int64)
+    twice = 0
+    for t in range(n_t):
+        want = ko.analyse_target(seqs[t], "t%d" % t, cpu)
+        assert [km.unpack(x, k) for x in res["node_kmer"][noff[t]:noff[t + 1]]] == want["kmers"], t
+        got = [kmlib.expand_path(res, p).tolist() for p in range(poff[t], poff[t + 1])]
+        assert got == [list(p) for p in want["paths"]], t
+        assert res["path_min_cov"][poff[t]:poff[t + 1]].tolist() == list(want["min_cov"]), t
+        twice += any(int(res["run_off"][p + 1] - res["run_off"][p]) == 4 for p in range(poff[t], poff[t + 1]))
+    assert twice >= 30, twice
+    b.close()
+    db.close()
+
+
 def test_table_fetches_are_counted_on_request_only():
     """KM_RUN_COUNT_FETCHES: sizes.table_fetches counts the 16-byte slots the walk read — a diagnostic that costs
     k_seed two ballots and an atomic per wave, so it is 0 unless asked for; the results do not depend on it."""
