@@ -258,9 +258,22 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     t_ = a0.tids ? a0.tids[blockIdx.x] : blockIdx.x;
   } else {
     const uint32_t n_first = a0.dfs_answers ? a0.work_n[2] : a0.work_n[0];
-    if (blockIdx.x >= n_first + a0.work_n[1]) return;
-    t_ = blockIdx.x < n_first ? (a0.dfs_answers ? a0.left[blockIdx.x] : a0.work_list[blockIdx.x])
-                              : a0.work_list[a0.work_n[0] + (blockIdx.x - n_first)];
+    const uint32_t n_total = n_first + a0.work_n[1];
+    auto entry = [&](uint32_t e) -> uint32_t {
+      return e < n_first ? (a0.dfs_answers ? a0.left[e] : a0.work_list[e]) : a0.work_list[a0.work_n[0] + (e - n_first)];
+    };
+    // The grid may be smaller than the batch (kmgpu.hip: launch_graph — when the epilogue of k_dfs answers the
+    // regular targets the list is a percent of the batch, and one block per TARGET meant 40 000 waves a step
+    // launched to read two words): entries beyond the grid go to the large tier, as any target does that
+    // outgrows this one — block 0 says so, the host reruns them (km_batch_sync).
+    if (blockIdx.x == 0 && n_total > gridDim.x) {
+      for (uint32_t e = gridDim.x + threadIdx.x; e < n_total; e += GRAPH_THREADS) {
+        const uint32_t tt = entry(e);
+        if (a0.status[tt] == T_OK) { a0.g_status[tt] = T_NEEDS_BIG; a0.t_npaths[tt] = 0; a0.t_pathbase[tt] = 0; a0.t_nruns[tt] = 0; }
+      }
+    }
+    if (blockIdx.x >= n_total) return;
+    t_ = entry(blockIdx.x);
   }
   const uint32_t t = t_;
   GraphArgs a = a0;

@@ -673,6 +673,7 @@ struct Knobs {
   bool seed_stamps = false;     // KM_SEED_STAMPS: in-kernel time stamps (results unchanged, slower)
   bool host_trace = false;      // KM_TRACE_HOST: host time of the sections of km_batch_run on stderr
   long spin_us = 0;             // KM_SPIN_US: poll the delivery event this long before sleeping on it
+  uint32_t graph_grid = 0;      // KM_GRAPH_GRID: blocks of k_graph when the epilogue of k_dfs is on (tests: force the overflow path)
 };
 Knobs read_knobs() {
   Knobs q;
@@ -687,6 +688,7 @@ Knobs read_knobs() {
   q.seed_stamps = getenv("KM_SEED_STAMPS") != nullptr;
   q.host_trace = getenv("KM_TRACE_HOST") != nullptr;
   q.spin_us = num("KM_SPIN_US", 0);
+  q.graph_grid = (uint32_t)std::max<long>(0, num("KM_GRAPH_GRID", 0));
   return q;
 }
 const Knobs& knobs() {
@@ -1248,8 +1250,17 @@ static void launch_pure(km_batch* b, hipStream_t st, const GraphArgs& ga) {
   else hipLaunchKernelGGL((k_graph_pure<0>), dim3(b->n_targets), dim3(64), b->pure_lds, st, ga);
 }
 static void launch_graph(km_batch* b, hipStream_t st, const GraphArgs& ga) {
-  if (ga.k == 31) hipLaunchKernelGGL((k_graph<false, 31>), dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
-  else hipLaunchKernelGGL((k_graph<false, 0>), dim3(b->n_targets), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+  // One block per entry of the work list.  When the epilogue of k_dfs answers the regular targets the list is a
+  // percent of the batch: a grid of an eighth of the batch (at least 1 024 blocks; KM_GRAPH_GRID sets it) instead
+  // of one block per target, of which nearly all left at once; should more be left than that, the kernel hands
+  // the rest to the large tier (graph_kernel.h).
+  uint32_t grid = b->n_targets;
+  if (ga.work_list && ga.dfs_answers) {
+    const uint32_t cap = knobs().graph_grid ? knobs().graph_grid : std::max<uint32_t>(1024u, b->n_targets / 8);
+    grid = std::min<uint32_t>(grid, cap);
+  }
+  if (ga.k == 31) hipLaunchKernelGGL((k_graph<false, 31>), dim3(grid), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
+  else hipLaunchKernelGGL((k_graph<false, 0>), dim3(grid), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
 }
 
 // Graph stage on one stream: pure-chain pass, then the general kernel for the rest.

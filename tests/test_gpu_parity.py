@@ -1344,6 +1344,16 @@ def test_epilogue_of_k_dfs_answers_bubbles_and_changes_nothing(k, tmp_path):
     for name in ("status", "n_ref", "probes", "node_off", "node_kmer", "node_count", "path_off", "run_off", "run_start",
                  "run_len", "path_len", "path_min_cov"):
         assert np.array_equal(on[name], off[name]), name
+    # the grid of k_graph is a fraction of the batch when the epilogue is on; entries beyond it go to the large
+    # tier: forced here with a grid of 4 blocks (KM_GRAPH_GRID) — the same arrays again
+    out2 = str(tmp_path / "grid4.npz")
+    env2 = dict(os.environ, KM_GRAPH_GRID="4")
+    subprocess.check_call([sys.executable, "-c", _EPI_CHILD % {"root": os.path.dirname(HERE), "spec": spec, "k": k, "out": out2}], env=env2)
+    small = np.load(out2)
+    assert int(small["left"][2]) == left > 4
+    for name in ("status", "n_ref", "probes", "node_off", "node_kmer", "node_count", "path_off", "run_off", "run_start",
+                 "run_len", "path_len", "path_min_cov"):
+        assert np.array_equal(on[name], small[name]), name
     co = c_oracle.COracle(case["keys"], case["counts"], k)
     noff, poff = on["node_off"].astype(np.int64), on["path_off"].astype(np.int64)
     multi = 0
