@@ -495,13 +495,14 @@ __device__ inline uint32_t bucket_of_wave(const TableView& t, uint64_t P) {
 // changed (the next bucket is loaded and evaluated) or the group does not exist.  A key never
 // leaves its bucket (probing wraps inside it), so "some slot of the bucket holds the tag" is exactly
 // the table's own answer.  Buckets of more than 64 * BUCKET_LANES_SETS slots are not held.
-constexpr uint32_t BUCKET_LANES_SETS = 9;          // slots per lane: buckets of up to 576 slots are held (a crowded
+constexpr uint32_t BUCKET_LANES_SETS = 7;          // slots per lane: buckets of up to 576 slots are held (a crowded
                                                    // bucket of the usual size, 4 * 128 + NC = 544 slots, fits)
 constexpr uint32_t SLOT_SINGLE = 4u, SLOT_HINT = 8u;
 struct BucketLanes {
   uint64_t tag[BUCKET_LANES_SETS];                           // lane j, set i: slot 64 i + j (EMPTY past the end)
-  uint64_t ntag[BUCKET_LANES_SETS];                          // tag of the group of the single kept child's suffix
   uint32_t info[BUCKET_LANES_SETS];                          // child base | SLOT_SINGLE | SLOT_HINT | count << 16
+  // (round 3 also kept the tag of the group the walk looks up next: two more registers per set, i.e. buckets of 256
+  // slots instead of 576 in the same registers; the walk works that tag out from the child, a dozen scalar instructions)
   uint32_t bucket, S;    // wave-uniform
   bool valid, resident;
 };
@@ -511,13 +512,14 @@ struct ChildRule {       // what get_child needs beside the counts (wave-uniform
   uint64_t thr_below;    // sums below it share the threshold thr_T (threshold_shortcut)
   uint32_t thr_T;
 };
-// One slot evaluated by its lane.  `keys` / `cap`: the walk's node set (the hint only).
-__device__ inline uint32_t set_home(uint64_t key, uint32_t cap);
+// One slot evaluated by its lane.  `hintf(k-mer)`: is it probably a node of the walk (the hint only).
+template <class HintF>
 __device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
-                                      const uint64_t* keys, uint32_t cap, uint64_t* ntag, uint32_t* info);
+                                      HintF& hintf, uint32_t* info);
 // lo / hi: the bucket's directory words (wave-uniform)
+template <class HintF>
 __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, uint32_t bucket, uint32_t lo, uint32_t hi,
-                                        const uint64_t* keys, uint32_t cap, BucketLanes* b, uint32_t* fetches) {
+                                        HintF& hintf, BucketLanes* b, uint32_t* fetches) {
   const uint32_t S = 2u * (hi - lo);
   b->bucket = bucket; b->S = S; b->valid = true; b->resident = S <= 64u * BUCKET_LANES_SETS;
   if (b->resident) {
@@ -526,7 +528,7 @@ __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, 
     // all the loads first (independent), then the evaluation
 #pragma unroll
     for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
-      b->tag[i] = EMPTY; b->ntag[i] = EMPTY; b->info[i] = 0; zw[i] = 0;
+      b->tag[i] = EMPTY; b->info[i] = 0; zw[i] = 0;
       if (64u * i < S) {                             // wave-uniform
         if (64u * i + lane < S) {
           const uint4 v = *reinterpret_cast<const uint4*>(t.slots + 2ull * lo + 64u * i + lane);
@@ -538,14 +540,14 @@ __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, 
 #pragma unroll
     for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
       if (64u * i < S) {                             // wave-uniform
-        if (b->tag[i] != EMPTY) slot_successor(t, r, b->tag[i], zw[i], keys, cap, &b->ntag[i], &b->info[i]);
+        if (b->tag[i] != EMPTY) slot_successor(t, r, b->tag[i], zw[i], hintf, &b->info[i]);
       }
     }
     *fetches += S;
   }
 }
 // the slot of the group `tag` in a resident bucket
-struct SlotHit { uint64_t ntag; uint32_t info; bool hit; };
+struct SlotHit { uint32_t info; bool hit; };
 // (nested, so that a hit leaves through one branch: a flat loop over the sets makes the compiler chain
 // an exit flag through every later set — sixteen taken branches behind a hit in the first one)
 // (no test of the set against the bucket's size: the sets a bucket does not reach hold EMPTY tags, which no
@@ -557,7 +559,6 @@ __device__ inline void bucket_find_from(const BucketLanes& b, uint64_t tag, Slot
     if (hit_) {
       const uint32_t l_ = (uint32_t)__ffsll((long long)hit_) - 1;
       h.info = lane_u32(b.info[I], l_);
-      h.ntag = lane_u64(b.ntag[I], l_);
       h.hit = true;
     } else {
       bucket_find_from<I + 1>(b, tag, h);
@@ -566,7 +567,7 @@ __device__ inline void bucket_find_from(const BucketLanes& b, uint64_t tag, Slot
 }
 __device__ inline SlotHit bucket_find_wave(const BucketLanes& b, uint64_t tag) {
   SlotHit h;
-  h.hit = false; h.info = 0; h.ntag = EMPTY;
+  h.hit = false; h.info = 0;
   bucket_find_from<0>(b, tag, h);
   return h;
 }
@@ -645,8 +646,9 @@ __device__ inline uint32_t child_mask(uint4 c, double ratio, double nc) {
 __device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) { return child_mask(c, ratio, (double)n_cutoff); }
 // device_common.h: BucketLanes.  What Jellyfish.get_child (km/utils/Jellyfish.py:55-72) makes of one
 // slot, for the k-mers x whose suffix x[1:] is the slot's (k-1)-mer in the orientation its side bit names.
+template <class HintF>
 __device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
-                                      const uint64_t* keys, uint32_t cap, uint64_t* ntag, uint32_t* info) {
+                                      HintF& hintf, uint32_t* info) {
   const uint32_t z = (uint32_t)zw, w = (uint32_t)(zw >> 32);
   const uint32_t s0 = z & 0xFFFFu, s1 = z >> 16, s2 = w & 0xFFFFu, s3 = w >> 16;   // slot order
   const bool esc = s0 == COUNT_ESCAPE || s1 == COUNT_ESCAPE || s2 == COUNT_ESCAPE || s3 == COUNT_ESCAPE;
@@ -658,29 +660,16 @@ __device__ inline void slot_successor(const TableView& t, const ChildRule& r, ui
   if (none) m4 = 0;
   const bool single = !esc && m4 != 0 && (m4 & (m4 - 1)) == 0;
   *info = 0;
-  *ntag = EMPTY;
   if (!single) return;
   const uint32_t si = (uint32_t)__ffs((int)m4) - 1;
   const uint32_t side = t.canonical ? (uint32_t)(tag & 1) : 0u;
   const uint32_t c = side ? 3u - si : si;                        // child base
   const uint32_t cnt = (uint32_t)(zw >> (16 * si)) & 0xFFFFu;
   const uint64_t G = tag >> 1;
-  // P: the (k-1)-mer as the walk reads it (x[1:]); R: its reverse complement
-  uint64_t P = G, R = 0;
-  if (t.canonical) {
-    const uint64_t Grc = revcomp(G, t.k - 1);
-    P = side ? Grc : G;
-    R = side ? G : Grc;
-  }
+  // P: the (k-1)-mer as the walk reads it (x[1:])
+  const uint64_t P = (t.canonical && side) ? revcomp(G, t.k - 1) : G;
   const uint64_t child = (P << 2) | c;                           // x[1:] + c, 2k bits
-  const uint64_t P2 = child & t.pmask;
-  uint64_t nt = P2 << 1;
-  if (t.canonical) {
-    const uint64_t R2 = (R >> 2) | ((uint64_t)(3u - c) << (2 * (t.k - 2)));
-    if (R2 < P2) nt = (R2 << 1) | 1ull;
-  }
-  *ntag = nt;
-  const bool hint = keys[set_home(child >> 2, cap)] == child;     // (the node set hashes by prefix: walk_kernel.h)
+  const bool hint = hintf(child);
   *info = c | SLOT_SINGLE | (hint ? SLOT_HINT : 0u) | (cnt << 16);
 }
 

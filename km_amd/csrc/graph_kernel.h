@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
   const uint32_t n_ref = a.n_ref[t];
   const uint64_t nb = a.node_base[t];
   const uint64_t h_woff = a.woff[t];
-  // (a flagged target's t_refmax belongs to k_dfs when its epilogue is on: it may be running right now)
+  // (a flagged target's t_refmax belongs to k_dfs when its epilogue is on — every exit of its fast tier writes it —
+  // and to k_graph, which resets it before it decides anything)
   if (tid == 0 && !(a.dfs_answers && h_tflag)) a.t_refmax[t] = NOT_BARE;
   if (h_status != T_OK) {
     if (tid == 0) { a.need_full[t] = 0; a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
@@ -313,6 +314,9 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     return;
   }
   if (a.use_need_full && !h_tflag && !h_need) return;   // answered by k_graph_pure
+  // whatever an earlier kernel or an earlier batch left there: only the bare-chain exit (1b, the same thread)
+  // names a maximum
+  if (tid == 0) a.t_refmax[t] = NOT_BARE;
   const uint32_t n = m + 2, src = m, snk = m + 1;
   const uint32_t ncap = a.ncap, hcap = a.hcap;
   if (n > ncap || (uint64_t)3 * n > (uint64_t)2 * hcap || (!BIG && n >= 0xFFFFu)) {

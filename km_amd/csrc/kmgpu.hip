@@ -84,24 +84,34 @@ __attribute__((constructor)) void km_default_hw_queues() { setenv("GPU_MAX_HW_QU
 constexpr int POOL_STREAMS = 7;                    // + the null stream: 8 hardware queues
 struct StreamPool {
   std::vector<hipStream_t> launch;
-  size_t next_launch = 0;
+  std::vector<char> in_use;                        // handed out by km_stream_create and not yet given back
 };
 std::mutex g_pool_mu;
 std::map<int, StreamPool> g_pools;
 
-// (device already current)
+// (device already current)  A pooled stream that nobody holds; once all are out, a fresh stream of the caller's
+// own (two consumers never share a launch stream: a capture on it, or a wait for its last batch, would see the
+// other's work).
 int pool_get(int device, hipStream_t* out) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   StreamPool& p = g_pools[device];
-  if (p.launch.empty())
+  if (p.launch.empty()) {
     for (int i = 0; i < POOL_STREAMS; ++i) { hipStream_t st = nullptr; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); p.launch.push_back(st); }
-  *out = p.launch[p.next_launch++ % p.launch.size()];
+    p.in_use.assign(p.launch.size(), 0);
+  }
+  for (size_t i = 0; i < p.launch.size(); ++i)
+    if (!p.in_use[i]) { p.in_use[i] = 1; *out = p.launch[i]; return KM_OK; }
+  hipStream_t st = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *out = st;
   return KM_OK;
 }
-bool pool_owns(hipStream_t st) {
+// true: a pool stream (now free again); false: not ours to keep
+bool pool_give_back(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   for (auto& kv : g_pools)
-    for (hipStream_t x : kv.second.launch) if (x == st) return true;
+    for (size_t i = 0; i < kv.second.launch.size(); ++i)
+      if (kv.second.launch[i] == st) { kv.second.in_use[i] = 0; return true; }
   return false;
 }
 }  // namespace
@@ -115,9 +125,10 @@ extern "C" int km_stream_create(int device, void** stream) {
   *stream = st;
   return KM_OK;
 }
-// (pool streams live as long as the process: handing one back is a no-op)
+// (pool streams live as long as the process: one handed back is free for the next km_stream_create; a stream made
+// beyond the pool is destroyed)
 extern "C" int km_stream_destroy(void* stream) {
-  if (stream && !pool_owns((hipStream_t)stream)) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  if (stream && !pool_give_back((hipStream_t)stream)) HIPCHK(hipStreamDestroy((hipStream_t)stream));
   return KM_OK;
 }
 
@@ -415,14 +426,17 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
       const uint32_t n_list = (uint32_t)meta[6];
       const uint32_t lds = 128u << 10;
       // (per device and cheap: set on every build rather than remembered per process)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_table_settle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_table_settle), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return bail(KM_E_HIP, "table settle pass: 128 KB of dynamic LDS refused", e);
       const uint32_t race_probe = max_probe;
       const unsigned long long n_slots_total = meta[5];
       (void)hipMemsetAsync(d_meta + 3, 0, 8, st);
       (void)hipMemsetAsync(d_meta + 5, 0, 8, st);
       hipLaunchKernelGGL(k_table_settle, dim3(n_list), dim3(256), lds, st, tv, slots, settle_list, n_list, lds, caps,
                          final_round, d_meta);
-      e = hipMemcpyAsync(meta, d_meta, 64, hipMemcpyDeviceToHost, st);
+      // (a rejected launch would leave meta[3] = 0, i.e. max_probe 2 with keys further out: lookups would miss them)
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(meta, d_meta, 64, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) return bail(KM_E_HIP, "table settle pass failed", e);
       max_probe = std::max<uint32_t>(2, (uint32_t)meta[3] + 1);
@@ -674,6 +688,7 @@ struct Knobs {
   bool host_trace = false;      // KM_TRACE_HOST: host time of the sections of km_batch_run on stderr
   long spin_us = 0;             // KM_SPIN_US: poll the delivery event this long before sleeping on it
   uint32_t graph_grid = 0;      // KM_GRAPH_GRID: blocks of k_graph when the epilogue of k_dfs is on (tests: force the overflow path)
+  bool speculate = true;        // KM_SPECULATE=0: k_dfs walks every chain one lookup after the other (results unchanged)
 };
 Knobs read_knobs() {
   Knobs q;
@@ -689,6 +704,7 @@ Knobs read_knobs() {
   q.host_trace = getenv("KM_TRACE_HOST") != nullptr;
   q.spin_us = num("KM_SPIN_US", 0);
   q.graph_grid = (uint32_t)std::max<long>(0, num("KM_GRAPH_GRID", 0));
+  q.speculate = num("KM_SPECULATE", 1) != 0;
   return q;
 }
 const Knobs& knobs() {
@@ -1120,6 +1136,7 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.g_ws = nullptr;
   a.g_stride = 0;
   a.dbg = knobs().debug_flags & 0xFFu;          // timing ablations (diagnostics build only); results are invalid
+  a.spec = knobs().speculate ? 1u : 0u;
 }
 
 static void fill_graph_args(km_batch* b, GraphArgs& g) {
@@ -1176,15 +1193,19 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
 // rest of its batch.
 static uint32_t words_cap_for(uint32_t len) { return round_up((len + 31) / 32 + 1, 2); }
 
-// slots of k_dfs's node set in the fast tier: load <= 0.55 with every allowed extra node in it
-static uint32_t walk_hs_cap(uint32_t nref) { return round_up((uint32_t)(((uint64_t)(nref + FAST_EXTRA) * 9 + 4) / 5), 64); }
+// slots of k_dfs's node set in the fast tier.  It holds the walk's nodes, the stack, and the target k-mers that lost
+// their slot of the position table (a fifth of them with the table at load 1/2): room for a quarter of the target's
+// k-mers + every allowed extra node + 64 frames, at load <= 3/4 (what does not fit goes to the large tier)
+static uint32_t walk_hs_cap(uint32_t nref) { return round_up((uint32_t)(((uint64_t)(nref / 4 + FAST_EXTRA + 64) * 4 + 2) / 3), 64); }
+// slots of its position table: the power of two >= twice the target's k-mers
+static uint32_t walk_pcap(uint32_t nref) { uint32_t p = 64; while (p < 2 * nref) p <<= 1; return p; }
 
 static bool fast_fits(const km_batch* b, uint32_t nref, uint32_t bcap) {
   const uint32_t len = nref + (uint32_t)b->db->k - 1;
   const uint32_t wc = words_cap_for(len);
   const uint32_t hs = walk_hs_cap(nref);
   const uint32_t ncap = nref + FAST_EXTRA + 2, hcap = round_up(ncap + ncap / 2 + 1, 64);
-  return walk_lds_bytes(hs, wc, bcap) <= FAST_LDS_LIMIT &&
+  return walk_lds_bytes(hs, wc, bcap, walk_pcap(nref), 2) <= FAST_LDS_LIMIT &&
          graph_ws_bytes<uint16_t>(ncap, hcap, wc) <= FAST_LDS_LIMIT && ncap < 0xFFFF &&
          (uint64_t)hcap * 4 + (uint64_t)wc * 8 <= FAST_LDS_LIMIT;
 }
@@ -1206,11 +1227,12 @@ static void fast_geometry(km_batch* b) {
   WalkArgs& wa = b->wa;
   fill_walk_args(b, wa);
   wa.hs_cap = walk_hs_cap(nref);
+  wa.pcap = walk_pcap(nref);
   wa.words_cap = words_cap_for(len);
   wa.fcap = round_up(std::min<uint32_t>(b->p.max_stack, FAST_FCAP_MAX - 2) + 2, 2);
   wa.bcap = bcap;
   wa.f_stride = walk_frame_bytes(wa.fcap);
-  b->walk_lds = (uint32_t)walk_lds_bytes(wa.hs_cap, wa.words_cap, wa.bcap);
+  b->walk_lds = (uint32_t)walk_lds_bytes(wa.hs_cap, wa.words_cap, wa.bcap, wa.pcap, 2);
   GraphArgs& ga = b->ga;
   fill_graph_args(b, ga);
   ga.ncap = nref + FAST_EXTRA + 2;
@@ -1595,10 +1617,11 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   const uint64_t hs = 2 * (max_nodes + b->p.max_stack + 64);
   if (hs > 0x7FFFFF00ull) return fail(KM_E_ARG, "node limit too large");
   a.hs_cap = round_up((uint32_t)hs, 64);
+  a.pcap = walk_pcap(max_nref);
   a.words_cap = words_cap_for(b->max_len);
   a.fcap = round_up(b->p.max_stack + 2, 2);
   a.bcap = b->p.max_break + 1;
-  a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap);
+  a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap, a.pcap);
   // run in slices so the workspace stays bounded
   const uint64_t budget = 8ull << 30;
   uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb, budget / a.g_stride));

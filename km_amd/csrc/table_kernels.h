@@ -349,13 +349,13 @@ __global__ __launch_bounds__(256) void k_table_settle(TableView t, Slot* slots, 
                                                       uint32_t lds_bytes, uint32_t* caps, int final,
                                                       unsigned long long* meta) {
   extern __shared__ __align__(16) unsigned char settle_lds[];
-  __shared__ uint32_t n_e_s, n_gather_s, maxstep_s;
+  __shared__ uint32_t n_e_s, n_gather_s, maxstep_s, unplaced_s;
   const uint32_t tid = threadIdx.x;
   const uint32_t bucket = list[blockIdx.x];
   const uint32_t lo = t.dir[bucket], hi = t.dir[bucket + 1];
   const uint32_t S = (uint32_t)bucket_slots(lo, hi);
   Slot* base = slots + 2ull * lo;
-  if (tid == 0) { n_e_s = 0; n_gather_s = 0; maxstep_s = 0; }
+  if (tid == 0) { n_e_s = 0; n_gather_s = 0; maxstep_s = 0; unplaced_s = 0; }
   __syncthreads();
   // the probe sequence of a group, from its tag alone (the tag names the (k-1)-mer and its orientation)
   auto sequence_of = [&](uint64_t tag, uint32_t* home, uint32_t* second) {
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void k_table_settle(TableView t, Slot* slots, 
   while (P2 < n_e) P2 <<= 1;
   // LDS: the new layout (S slots), then per group: tag, old slot, home, second pair, new slot
   const uint64_t need = (uint64_t)S * sizeof(Slot) + (uint64_t)P2 * (8 + 4 * 4);
-  if (S > 0xFFFFu || need > lds_bytes) {
-    // measure only: how far along its sequence does every group sit?
+  // measure only (the bucket stays as the race built it): how far along its sequence does every group sit?
+  auto measure_only = [&]() {
     uint32_t far = 0;
     for (uint32_t i = tid; i < S; i += 256) {
       const uint64_t tag = base[i].tag;
@@ -396,6 +396,9 @@ __global__ __launch_bounds__(256) void k_table_settle(TableView t, Slot* slots, 
       if (!final && maxstep_s >= 4 && cap_gen(caps[bucket]) < CAP_HARD_GEN && !(atomicOr(&caps[bucket], CAP_GROW) & CAP_GROW))
         atomicAdd(&meta[2], 1ull);
     }
+  };
+  if (S > 0xFFFFu || need > lds_bytes) {
+    measure_only();
     return;
   }
   Slot* A = reinterpret_cast<Slot*>(settle_lds);
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(256) void k_table_settle(TableView t, Slot* slots, 
       if (A[h].tag == EMPTY) { A[h].tag = tags[e]; new_at[e] = h; }
       else if (A[h + 1].tag == EMPTY) { A[h + 1].tag = tags[e]; new_at[e] = h + 1; }
     }
+    bool unplaced = false;
     for (uint32_t e = 0; e < n_e; ++e) {
       if (new_at[e] != 0xFFFFFFFFu) continue;
       uint32_t idx = second_at[e];
@@ -453,13 +457,24 @@ __global__ __launch_bounds__(256) void k_table_settle(TableView t, Slot* slots, 
         if (A[idx].tag == EMPTY) { A[idx].tag = tags[e]; new_at[e] = idx; far = max(far, step); break; }
         if (++idx == S) idx = 0;
       }
+      // (the sequence visits S - 2 slots behind the home pair, not the whole ring: a group may find none of them
+      // free where the race, in another order, placed every group)
+      if (new_at[e] == 0xFFFFFFFFu) { unplaced = true; break; }
     }
-    if (far >= 2) atomicMax(&meta[3], (unsigned long long)far);
-    // a group that fits neither of its pairs: the bucket gets its one further doubling (and the table another round)
-    if (!final && far >= 4 && cap_gen(caps[bucket]) < CAP_HARD_GEN && !(atomicOr(&caps[bucket], CAP_GROW) & CAP_GROW))
-      atomicAdd(&meta[2], 1ull);
+    if (unplaced) {
+      unplaced_s = 1;
+    } else {
+      if (far >= 2) atomicMax(&meta[3], (unsigned long long)far);
+      // a group that fits neither of its pairs: the bucket gets its one further doubling (and the table another round)
+      if (!final && far >= 4 && cap_gen(caps[bucket]) < CAP_HARD_GEN && !(atomicOr(&caps[bucket], CAP_GROW) & CAP_GROW))
+        atomicAdd(&meta[2], 1ull);
+    }
   }
   __syncthreads();
+  if (unplaced_s) {                                      // nothing has been written back: the race's layout stands
+    measure_only();
+    return;
+  }
   for (uint32_t e = tid; e < n_e; e += 256) {
     const Slot src = base[old_at[e]];
     Slot& dst = A[new_at[e]];

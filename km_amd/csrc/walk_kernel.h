@@ -135,11 +135,14 @@ struct WalkArgs {
   unsigned long long* dfs_probes;  // per target, written by k_dfs
   unsigned long long* fetches;
   // k_dfs workspace geometry (LDS for the fast tier, per-block global for BIG)
-  uint32_t hs_cap;      // node-set slots, multiple of 64
+  uint32_t hs_cap;      // node-set slots, multiple of 64 (walk-discovered k-mers, the stack, and the few target
+                        // k-mers that lost their slot of the position table)
+  uint32_t pcap;        // position-table slots (a power of two >= 64): the target's own k-mers by (k-1)-mer prefix
   uint32_t words_cap;   // packed-target words (even)
   uint32_t fcap;        // stack frames (even) >= max_stack + 2
   uint32_t bcap;        // branch frames >= max_break + 1
   uint32_t dbg;         // diagnostic ablation flags (KM_DEBUG_FLAGS): 1 = skip k_dfs work
+  uint32_t spec;        // k_dfs: look a chain up along the target, one predicted step per lane (KM_SPECULATE=0: off; same results)
   unsigned char* g_ws;  // BIG only
   uint64_t g_stride;    // BIG only: bytes per block
   unsigned char* f_ws;  // fast tier: global scratch for the DFS stack frames (per block)
@@ -154,17 +157,20 @@ struct WalkArgs {
 __host__ __device__ inline uint64_t walk_frame_bytes(uint32_t fcap) {
   return (((uint64_t)fcap * 16) + 15) & ~15ull;       // k-mer 8 + count 4 + set slot 4
 }
-__host__ __device__ inline uint64_t walk_lds_bytes(uint32_t hs_cap, uint32_t words_cap, uint32_t bcap) {
+// pos_elt: bytes per entry of the position table (2 in the LDS tier, 4 in the large one)
+__host__ __device__ inline uint64_t walk_lds_bytes(uint32_t hs_cap, uint32_t words_cap, uint32_t bcap, uint32_t pcap,
+                                                   uint32_t pos_elt) {
   uint64_t b = 0;
   b += (uint64_t)hs_cap * 8;       // keys
   b += (uint64_t)words_cap * 8;    // packed target
   b += (uint64_t)bcap * 32;        // branch frames
   b += (uint64_t)hs_cap * 2;       // slot states + node indices (slot_meta)
+  b += (uint64_t)pcap * pos_elt;   // position table
   return (b + 15) & ~15ull;
 }
 __host__ __device__ inline uint64_t walk_ws_bytes(uint32_t hs_cap, uint32_t words_cap,
-                                                  uint32_t fcap, uint32_t bcap) {
-  return walk_lds_bytes(hs_cap, words_cap, bcap) + walk_frame_bytes(fcap);
+                                                  uint32_t fcap, uint32_t bcap, uint32_t pcap) {
+  return walk_lds_bytes(hs_cap, words_cap, bcap, pcap, 4) + walk_frame_bytes(fcap);
 }
 
 // Home slot in an LDS key set.  A cheap 32-bit mix (two multiplies) instead of a 64-bit
@@ -555,8 +561,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
 #define KM_DFS_STAMP(n) do {} while (0)
 #endif
 
+// (the register allocator is told how many waves a SIMD is to hold: 512 / 4 = 128 vector registers)
+#ifndef KM_DFS_WAVES_PER_EU
+#define KM_DFS_WAVES_PER_EU 4
+#endif
 template <bool BIG, int K>
-__global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES_PER_EU))) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef KM_DFS_STAMPS
   uint32_t dfs_entry;
@@ -572,6 +582,19 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   // diagnostics (KM_SEED_STAMPS in the environment): when this wave started and ended, 100 MHz clock
   unsigned long long life0 = 0, life1 = 0, life2 = 0, lifeB = 0, lifeC = 0;
   if (a.stamps) life0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef KM_DFS_COUNTERS
+  uint32_t dc_slow = 0, dc_spec = 0, dc_rec = 0, dc_bload = 0, dc_gen = 0, dc_runs = 0, dc_full = 0, dc_v0 = 0, dc_steps = 0, dc_noalign = 0;
+  uint32_t dt_spec = 0, dt_book = 0, dt_gen = 0, dt_bload = 0, dt_rejoin = 0, dt_unwind = 0, dt_align = 0, dt_t0 = 0;   // 10 ns units
+#define KM_DC(x) (++(x))
+#define KM_DCN(x, v) ((x) += (v))
+#define KM_DT0() (dt_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime())
+#define KM_DT(x) do { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memrealtime(); (x) += n_ - dt_t0; dt_t0 = n_; } while (0)
+#else
+#define KM_DC(x) do {} while (0)
+#define KM_DCN(x, v) do {} while (0)
+#define KM_DT0() do {} while (0)
+#define KM_DT(x) do {} while (0)
 #endif
   const TableView tab = specialized_view<K>(a.tab);
   const int k = tab.k;
@@ -603,7 +626,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   unsigned char* fwb;
   if constexpr (BIG) {
     wsb = a.g_ws + (uint64_t)blockIdx.x * a.g_stride;
-    fwb = wsb + walk_lds_bytes(a.hs_cap, a.words_cap, a.bcap);
+    fwb = wsb + walk_lds_bytes(a.hs_cap, a.words_cap, a.bcap, a.pcap, 4);
   } else {
     wsb = smem;
     fwb = a.f_ws + (uint64_t)blockIdx.x * a.f_stride;
@@ -613,6 +636,20 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   uint64_t* words = keys + cap;
   BranchFrame* bf = reinterpret_cast<BranchFrame*>(words + a.words_cap);
   uint16_t* state = reinterpret_cast<uint16_t*>(bf + a.bcap);
+  // The target's own k-mers are NOT entered into the node set: a table of POSITIONS hashed by (k-1)-mer prefix,
+  // written with plain stores (whoever stores last owns a slot), answers "is y the target's k-mer i" by reading the
+  // slot and comparing y with the packed target at that position.  The k-mers that lost their slot (a fifth of
+  // them at load 1/2) go into the node set as before.  Set-up was the compare-and-swap of all of a target's k-mers —
+  // bound by the LDS atomic rate of a CU whose waves build their sets at the same time — and the 64-bit keys of
+  // those k-mers were three quarters of a wave's LDS.
+  using pos_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
+  constexpr uint32_t POS_NONE = (uint32_t)(pos_t)~(pos_t)0, NO_NODE = 0xFFFFFFFFu;
+  pos_t* pos = reinterpret_cast<pos_t*>(state + cap);
+  const uint32_t pcap = a.pcap;
+  // its hash looks at the low 32 bits of the prefix only (the last 16 bases: one multiply, and the set-up reads them
+  // straight off the packed target with 32-bit operations); pcap is a power of two
+  const uint32_t pshift = 32u - (uint32_t)__ffs((int)pcap) + 1u;
+  auto pos_home = [&](uint32_t p32) -> uint32_t { return (p32 * 0x9E3779B1u) >> pshift; };
   uint64_t* fk = reinterpret_cast<uint64_t*>(fwb);
   uint32_t* fc = reinterpret_cast<uint32_t*>(fk + a.fcap);
   uint32_t* fs = fc + a.fcap;
@@ -630,8 +667,12 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   const uint32_t nwords = (uint32_t)(((uint64_t)n_ref + (uint32_t)k - 1 + 31) >> 5);
   const uint32_t nflag = (n_ref + 31) >> 5;
   const uint32_t* flag = a.flagbits + fwo;
-  if (nwords + 1 > a.words_cap || n_ref > node_cap || (uint64_t)n_ref * 4 > (uint64_t)cap * 3) {
-    if (lane == 0) a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG;
+  if (nwords + 1 > a.words_cap || n_ref > node_cap || (uint64_t)n_ref * 4 > (uint64_t)pcap * 3 || n_ref >= POS_NONE) {
+    if (lane == 0) {
+      a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG;
+      // (with the epilogue on, a flagged target's t_refmax is this kernel's to write: k_graph_pure leaves it alone)
+      if constexpr (!BIG) { if (a.epi != nullptr) a.epi->t_refmax[t] = NOT_BARE; }
+    }
     return;
   }
   if (a.dbg & 1u) return;
@@ -647,13 +688,16 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
 #endif
   if constexpr (BIG) {
     for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
+    for (uint32_t s = lane; s < pcap; s += 64) pos[s] = (pos_t)POS_NONE;
   } else {
-    // LDS: 16 bytes per store (cap is a multiple of 64: whole uint4s in both arrays)
+    // LDS: 16 bytes per store (cap and pcap are multiples of 64: whole uint4s in all three arrays)
     const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     uint4* kq = reinterpret_cast<uint4*>(keys);
     for (uint32_t s = lane; s < cap / 2; s += 64) kq[s] = ones;
     uint4* sq = reinterpret_cast<uint4*>(state);
     for (uint32_t s = lane; s < cap / 8; s += 64) sq[s] = make_uint4(0u, 0u, 0u, 0u);
+    uint4* pq = reinterpret_cast<uint4*>(pos);
+    for (uint32_t s = lane; s < pcap / 8; s += 64) pq[s] = ones;
   }
   __syncthreads();
   auto kmer_at = [&](uint32_t i) -> uint64_t {
@@ -662,6 +706,48 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
     const uint64_t x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
     return x >> (64 - 2 * k);
   };
+  // low 32 bits of the (k-1)-mer prefix of the target's k-mer i: bases i + k - 17 .. i + k - 2, read as 32-bit pieces
+  // of the packed words (piece j = bases 16 j .. 16 j + 15 is element j ^ 1 of the little-endian 64-bit words)
+  auto prefix32_at = [&](uint32_t i) -> uint32_t {
+    if (k >= 17) {
+      const uint32_t b0 = i + (uint32_t)k - 17u, j = b0 >> 4, sh = (b0 & 15u) * 2u;
+      const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
+      const uint32_t hi = w32[j ^ 1u], lo = w32[(j + 1u) ^ 1u];
+      return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+    }
+    return (uint32_t)(kmer_at(i) >> 2);
+  };
+  // the index of the target k-mer y, if y is one that owns its slot of the position table (the others are in the node set)
+  auto ref_index = [&](uint64_t y) -> uint32_t {
+    const uint32_t p_ = (uint32_t)pos[pos_home((uint32_t)(y >> 2))];
+    if (p_ == POS_NONE) return NO_NODE;
+    return kmer_at(p_) == y ? p_ : NO_NODE;
+  };
+  // y is probably a node (a target k-mer, or a k-mer sitting in its home slot of the node set): a hint
+  auto node_hint = [&](uint64_t y) -> bool { return ref_index(y) != NO_NODE || keys[set_home(y >> 2, cap)] == y; };
+  // ---- for the speculation of the chain runs (below): where do x's last SPEC_ELL bases occur in the target?  Lane l
+  // keeps the SPEC_ELL-mers starting at positions l, l + 64, ... (16 bits each, two per register: the first
+  // 64 * 2 * SPEC_PK positions of the target; a longer target is simply not searched beyond them)
+  constexpr uint32_t SPEC_ELL = 8, SPEC_PK = 4;
+  const uint32_t Lb = n_ref + (uint32_t)k - 1;               // bases of the target
+  auto win64 = [&](uint32_t p) -> uint64_t {                 // 32 bases from target position p (zeros past the end)
+    const uint32_t w = p >> 5, sh = (p & 31) * 2;
+    const uint64_t hi = words[w], lo = words[w + 1];
+    return sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+  };
+  const bool spec_ell_ok = a.spec != 0 && (uint32_t)k > 2 * SPEC_ELL && Lb > SPEC_ELL;
+  uint32_t ell_pk[SPEC_PK];
+#pragma unroll
+  for (uint32_t q = 0; q < SPEC_PK; ++q) ell_pk[q] = 0;
+  if (spec_ell_ok) {
+#pragma unroll
+    for (uint32_t q = 0; q < 2 * SPEC_PK; ++q) {
+      const uint32_t p = lane + 64u * q;
+      uint32_t v = 0;
+      if (p + SPEC_ELL < Lb) v = (uint32_t)(win64(p) >> (64 - 2 * SPEC_ELL));
+      ell_pk[q >> 1] |= (q & 1u) ? (v << 16) : v;
+    }
+  }
 #ifndef KM_DFS_STAMPS
   if (a.stamps) lifeC = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -670,58 +756,41 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   // last one's suffix is nobody's prefix — is read off this very build: the set hashes a k-mer by its
   // prefix, so k-mers sharing one follow the same probe sequence and the later one meets the earlier.
   uint32_t shared = 0;
-  // four k-mers per lane and round: their first compare-and-swaps are in flight together (an LDS
-  // atomic returns after ~130 cycles; one after the other they were a quarter of the kernel's
-  // fixed cost); the few that find their home slot taken probe on afterwards
-  {
-    uint64_t pend_k[4];
-    uint32_t pend_sl[4], pend_i[4], n_pend = 0;
-    for (uint32_t i0 = lane; i0 < n_ref; i0 += 256) {
-      uint64_t kk[4];
-      uint32_t hs[4];
-      unsigned long long old[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + 64 * u;
-        kk[u] = i < n_ref ? kmer_at(i) : 0;
-        hs[u] = set_home(kk[u] >> 2, cap);
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        old[u] = EMPTY;
-        if (i0 + 64 * u < n_ref) {
-          old[u] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[hs[u]]), (unsigned long long)EMPTY, (unsigned long long)kk[u]);
-        }
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        if (i0 + 64 * u >= n_ref) continue;
-        if (old[u] == EMPTY) { state[hs[u]] = slot_meta(ST_NODE, i0 + 64 * u); continue; }
-        if (old[u] == kk[u]) { dup = 1; continue; }
-        if ((old[u] >> 2) == (kk[u] >> 2)) shared = 1;
-#pragma unroll
-        for (uint32_t v = 0; v < 4; ++v) if (v == n_pend) { pend_k[v] = kk[u]; pend_sl[v] = hs[u]; pend_i[v] = i0 + 64 * u; }
-        ++n_pend;
-      }
-      // one retry loop for everything that found its home slot taken (see the fingerprint phase)
-      uint32_t guard = 0;
-      while (__any((int)(n_pend != 0))) {
-        if (++guard > 4 * cap) { dup = 1; break; }          // cannot happen (the set is at most 3/4 full)
-        if (n_pend) {
-          uint32_t sl = pend_sl[0] + 1;
-          if (sl == cap) sl = 0;
-          const unsigned long long o2 = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)EMPTY,
-                                                  (unsigned long long)pend_k[0]);
-          if (o2 != EMPTY && o2 != pend_k[0] && (o2 >> 2) == (pend_k[0] >> 2)) shared = 1;
-          if (o2 == EMPTY || o2 == pend_k[0]) {
-            if (o2 == EMPTY) state[sl] = slot_meta(ST_NODE, pend_i[0]);
-            else dup = 1;
-            --n_pend;
-#pragma unroll
-            for (uint32_t u = 0; u < 3; ++u) { pend_k[u] = pend_k[u + 1]; pend_sl[u] = pend_sl[u + 1]; pend_i[u] = pend_i[u + 1]; }
-          } else {
-            pend_sl[0] = sl;
-          }
+  // Pass 1: every target k-mer stores its index at the slot of its prefix (plain stores; the last one wins).
+  // Pass 2: whoever does not read its own index back has lost the slot — to a k-mer with another prefix, or to
+  // one sharing its prefix (then the graph is not the plain chain: `shared`) or to its own twin (`dup`) — and is
+  // entered into the node set with compare-and-swap, as every target k-mer used to be.
+  uint32_t n_losers = 0;                                     // wave-uniform
+#pragma unroll 2
+  for (uint32_t i = lane; i < n_ref; i += 64) pos[pos_home(prefix32_at(i))] = (pos_t)i;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_ref; base += 64u * 32u) {       // (wave-uniform; one trip for targets of up to 2 048 k-mers)
+    // who lost its slot: up to 32 k-mers per lane, their reads of the table in flight together
+    uint32_t lost_bits = 0;
+#pragma unroll 8
+    for (uint32_t q = 0; q < 32; ++q) {
+      const uint32_t i = base + 64u * q + lane;
+      if (base + 64u * q >= n_ref) break;                             // wave-uniform
+      if (i < n_ref && (uint32_t)pos[pos_home(prefix32_at(i))] != i) lost_bits |= 1u << q;
+    }
+    // the losers, one after the other per lane (1.5 on average): compared with the owner of their slot, then entered
+    for (uint32_t bits = lost_bits; __any((int)(bits != 0)); bits &= bits - 1) {
+      const bool mine = bits != 0;
+      n_losers += (uint32_t)__popcll(__ballot(mine));
+      if (mine) {
+        const uint32_t i = base + 64u * ((uint32_t)__ffs((int)bits) - 1) + lane;
+        const uint64_t kk = kmer_at(i);
+        const uint64_t xw = kmer_at((uint32_t)pos[pos_home((uint32_t)(kk >> 2))]);   // (the slot was written: by this k-mer, if by no other)
+        if (xw == kk) dup = 1;
+        else if ((xw >> 2) == (kk >> 2)) shared = 1;
+        uint32_t sl = set_home(kk >> 2, cap);
+        for (uint32_t step = 0; step < cap && !dup; ++step) {
+          const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)EMPTY,
+                                                   (unsigned long long)kk);
+          if (old == EMPTY) { state[sl] = slot_meta(ST_NODE, i); break; }
+          if (old == kk) { dup = 1; break; }
+          if ((old >> 2) == (kk >> 2)) shared = 1;
+          if (++sl == cap) sl = 0;
         }
       }
     }
@@ -730,8 +799,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   bool ref_pure = false;
   if constexpr (!BIG) {
     if (a.epi != nullptr && n_ref >= 2) {
-      if (lane == 0) {                                       // whoever has the last suffix as its prefix sits in its cluster
-        const uint64_t S = kmer_at(n_ref - 1) & tab.pmask;
+      if (lane == 0) {                                       // whoever has the last suffix as its prefix owns its slot of the
+        const uint64_t S = kmer_at(n_ref - 1) & tab.pmask;   // position table or sits in its cluster of the node set
+        const uint32_t w = (uint32_t)pos[pos_home((uint32_t)S)];
+        if (w != POS_NONE && (kmer_at(w) >> 2) == S) shared = 1;
         uint32_t sl = set_home(S, cap);
         for (uint32_t step = 0; step < cap; ++step) {
           const uint64_t kv = keys[sl];
@@ -754,7 +825,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   BucketLanes bl;
   bl.valid = false; bl.resident = false; bl.bucket = 0; bl.S = 0;
 #pragma unroll
-  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) { bl.tag[i] = EMPTY; bl.ntag[i] = EMPTY; bl.info[i] = 0; }
+  for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) { bl.tag[i] = EMPTY; bl.info[i] = 0; }
   const ChildRule rule = {a.ratio, a.nc, a.thr_below, a.thr_T};
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
@@ -776,8 +847,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
 #endif
   // ---- exact DFS from every flagged seed, in target order ----------------------------
   if (st == T_OK) {
-    uint32_t set_count = n_ref;
+    uint32_t set_count = n_losers;
     const uint32_t set_limit = (uint32_t)(((uint64_t)cap * 3) >> 2);
+    // (a target whose k-mers crowd the position table — few distinct prefixes — leaves no room for the walk here)
+    if (set_count + 8 > set_limit) st = BIG ? T_INTERNAL : T_NEEDS_BIG;
     uint64_t steps = 0;
     for (uint32_t w = 0; w < nflag && st == T_OK; ++w) {
       // (word w of the flag bitmap: lane w & 63 of its chunk of 64 words holds it)
@@ -788,9 +861,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
         bits &= bits - 1;
         const uint32_t i = w * 32 + b;
         uint64_t cur = kmer_at(i);
-        bool fnd;
-        const int sslot = set_find<2>(keys, cap, cur, &fnd);
-        if (lane == 0) { fk[0] = cur; fc[0] = 0; fs[0] = (uint32_t)sslot; }
+        // (the seed is a node for good: its frame's set slot is never looked at)
+        if (lane == 0) { fk[0] = cur; fc[0] = 0; fs[0] = 0u; }
         uint32_t depth = 1, reg = 1, bsp = 0, parent_brk = 0, mask = 0, brk = 0;
         uint4 c4 = make_uint4(0, 0, 0, 0);
         bool need_expand = true;
@@ -800,6 +872,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
           KM_DFS_STAMP(0);                                 // loop control + whatever was not stamped
           if (need_expand) {
             need_expand = false;
+            KM_DT0();
             if (n_nodes > a.max_node) { st = T_NODE_LIMIT; break; }
             if (!(pend.valid && pend.X == cur)) children_issue_wave(tab, cur, &dcache, &pend);
             KM_DFS_STAMP(1);                               // a lookup that had not been requested ahead
@@ -807,6 +880,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             KM_DFS_STAMP(2);                               // wait for the pair + resolve
             pend.valid = false;
             probes_u += 4;
+            KM_DC(dc_gen);
+            KM_DT(dt_gen);
             mask = child_mask(c4, a.ratio, a.nc);
             brk = parent_brk;
             if (__popc(mask) > 1) {
@@ -857,12 +932,14 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             // From the second step on all of it comes precomputed out of the slot that named the
             // child (device_common.h: BucketLanes); only the first step works it out here.
             uint64_t child = ((x << 2) | c) & tab.kmask;
-            auto slow_state = [&](uint64_t ch, uint64_t* T_out, bool* hint_out) {
+            auto tag_of_suffix = [&](uint64_t ch) -> uint64_t {      // tag of the group of ch[1:]: what the expansion of ch looks up
               const uint64_t P = ch & tab.pmask;
               uint32_t flip_;
-              *T_out = group_tag(tab, P, revcomp(P, k - 1), &flip_);
-              const uint64_t at_home = keys[set_home(ch >> 2, cap)];
-              *hint_out = __builtin_amdgcn_readfirstlane((int)(at_home == ch)) != 0;
+              return group_tag(tab, P, revcomp(P, k - 1), &flip_);
+            };
+            auto slow_state = [&](uint64_t ch, uint64_t* T_out, bool* hint_out) {
+              *T_out = tag_of_suffix(ch);
+              *hint_out = __builtin_amdgcn_readfirstlane((int)node_hint(ch)) != 0;
             };
             uint64_t T;
             bool hint;
@@ -871,16 +948,136 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             // child — kept out of the loop's hot path; true: the run goes on, false: (c4, mask) hold the
             // expansion of x and the run ends
             auto step_slow = [&](bool was_hit) -> bool {
-              if (!was_hit) {
+              bool have_c4 = false;                        // c4 = the expansion of x (set by the speculation below)
+              KM_DC(dc_slow);
+              KM_DT0();
+              if (!was_hit && a.spec) {
+                // ---- speculation along the target.  Behind a variant the walk runs back onto the target: the
+                // k-mers of the chain are then x shifted by the target's own bases, known in advance — only
+                // whether the table agrees is not.  So the steps are looked up TOGETHER, lane j taking
+                // y_j = x + the next j bases of the target (one full lookup per lane, as k_seed does: key,
+                // directory word, home pair), and verified in order afterwards: step j stands iff get_child of
+                // y_j keeps exactly the predicted base (km/utils/Jellyfish.py:55-72).  What stands is recorded
+                // as children of the run, exactly as if it had been walked one lookup after the other; the
+                // first y_j that does not follow the prediction is a real k-mer of the chain with its real
+                // expansion, and the run goes on from there.  Lookups have no side effects: a wrong alignment
+                // costs their latency and nothing else.  Where the target's bases line up with x:
+                //  (a) a substitution does not shift the walk against the target: x, s steps behind the seed i,
+                //      then ends at target position i + k - 1 + s;
+                //  (b) else the last SPEC_ELL bases of x occur in the target (first occurrence).
+                constexpr uint32_t SPEC_NONE = 0xFFFFFFFFu;
+                uint32_t e = SPEC_NONE;                                  // target position of the base predicted next
+                // the k-mer at stack position s is the seed (target k-mer i) shifted by s bases: x, at position
+                // depth - 1 + n, ends at target position i + k - 1 + that if the walk has not shifted against the
+                // target — at the first k-mer off the target that is the hypothesis, later on x's last bases say
+                {
+                  const uint32_t sx = depth - 1 + n, e_sub = i + (uint32_t)k + sx;
+                  if (e_sub < Lb && e_sub >= (uint32_t)k) {
+                    const uint64_t d = x ^ kmer_at(e_sub - (uint32_t)k);
+                    const uint32_t agree = d ? ((uint32_t)__ffsll((long long)d) - 1) >> 1 : (uint32_t)k;
+                    // (the seed's other child — the k-mer at stack position 1 — ends on the substituted base: the
+                    // bases behind it agree, that one does not)
+                    if ((sx <= 4 && agree == sx - 1) || agree >= 4) e = e_sub;
+                  }
+                }
+                if (e == SPEC_NONE && spec_ell_ok) {
+                  const uint32_t sfx = (uint32_t)x & ((1u << (2 * SPEC_ELL)) - 1);
+                  uint32_t hits = 0;                                     // bit q: the SPEC_ELL-mer at lane + 64 q is x's suffix
+#pragma unroll
+                  for (uint32_t q = 0; q < 2 * SPEC_PK; ++q) {
+                    const uint32_t v = (q & 1u) ? (ell_pk[q >> 1] >> 16) : (ell_pk[q >> 1] & 0xFFFFu);
+                    if (v == sfx && lane + 64u * q + SPEC_ELL < Lb) hits |= 1u << q;
+                  }
+                  if (__any((int)(hits != 0))) {
+                    for (uint32_t q = 0; q < 2 * SPEC_PK; ++q) {         // first occurrence in target order
+                      const unsigned long long mm = __ballot((hits >> q) & 1u);
+                      if (mm) { e = 64u * q + (uint32_t)__ffsll((long long)mm) - 1 + SPEC_ELL; break; }
+                    }
+                  }
+                }
+                if (e == SPEC_NONE) KM_DC(dc_noalign);
+                KM_DT(dt_align);
+                if (e != SPEC_NONE) {
+                  // how many of x's last bases are the target's bases before e: the chain is back on the target (a
+                  // rejoin, surely a node) after k - lam more steps
+                  uint32_t lam;
+                  if (e >= (uint32_t)k) {
+                    const uint64_t d = x ^ kmer_at(e - (uint32_t)k);
+                    lam = d ? ((uint32_t)__ffsll((long long)d) - 1) >> 1 : (uint32_t)k;
+                  } else {
+                    const uint64_t d = (x ^ (win64(0) >> (64 - 2 * e))) & ((1ull << (2 * e)) - 1);   // (1 <= e < k <= 32)
+                    lam = d ? ((uint32_t)__ffsll((long long)d) - 1) >> 1 : e;
+                  }
+                  if (lam >= (uint32_t)k) {
+                    // x itself is a k-mer of the target, i.e. a node: the booking ends the run before it
+                    c4 = make_uint4(0, 0, 0, 0);
+                    mask = 0;
+                    expanded = true;
+                    return false;
+                  }
+                  // lanes 0 .. J-1 look up y_0 .. y_{J-1}; y_J is the target's k-mer at e + J - k when J = k - lam
+                  const uint32_t J_full = (uint32_t)k - lam;
+                  uint32_t J = min(J_full, 31u);
+                  J = min(J, Lb - e);
+                  J = min(J, room - n + 1);                              // (n <= room here)
+                  if (J >= 3) {
+                    const uint64_t w64 = win64(e);
+                    uint64_t yj = x;
+                    if (lane >= 1 && lane < J) yj = ((x << (2 * lane)) | (w64 >> (64 - 2 * lane))) & tab.kmask;
+                    const uint32_t pb = lane < J ? (uint32_t)(w64 >> (62 - 2 * lane)) & 3u : 4u;   // (e + lane < Lb)
+                    uint32_t fl = 0;
+                    const uint4 cj = forward_children(tab, yj, &fl);
+                    const uint32_t mj = child_mask(cj, a.ratio, a.nc);
+                    const bool single = mj != 0 && (mj & (mj - 1)) == 0;
+                    const uint32_t cbj = single ? (uint32_t)__ffs((int)mj) - 1 : 0u;
+                    const uint32_t cntj = pick4(cj, cbj);
+                    const unsigned long long badm = __ballot(!(single && cbj == pb));   // (pb = 4 from lane J on)
+                    const uint32_t V = (uint32_t)__ffsll((long long)badm) - 1;    // steps that stand (<= J)
+                    const uint32_t R = V == J ? J - 1 : V;               // children recorded: y_1 .. y_R
+                    {
+                      const uint64_t ys = (uint64_t)__shfl((unsigned long long)yj, (int)((lane - n + 1) & 63u));
+                      const uint32_t cs = (uint32_t)__shfl((int)cntj, (int)((lane - n) & 63u));
+                      if (lane >= n && lane < n + R) { rkey = ys; rcnt = cs; }
+                    }
+                    if (lane >= J) fl = 0;
+                    for (int o = 32; o > 0; o >>= 1) fl += __shfl_xor(fl, o);
+                    fetch_u += fl;
+                    n += R;
+                    KM_DC(dc_spec); KM_DCN(dc_rec, R);
+                    KM_DT(dt_spec);
+                    if (V == 0) KM_DC(dc_v0);
+                    if (V == J && J == J_full) KM_DC(dc_full);
+                    if (V == J) {
+                      // every step stands: y_{J-1} is the top of the run and has exactly the child y_J left —
+                      // a k-mer of the target (a node: the run ends before it) unless the lanes ran out first
+                      x = lane_u64(yj, J - 1);
+                      c = lane_u32(cbj, J - 1);
+                      cnt = lane_u32(cntj, J - 1);
+                      child = ((x << 2) | c) & tab.kmask;
+                      if (J == J_full) { hint = true; T = EMPTY; }
+                      else slow_state(child, &T, &hint);
+                      return true;
+                    }
+                    x = lane_u64(yj, V);
+                    c4 = make_uint4(lane_u32(cj.x, V), lane_u32(cj.y, V), lane_u32(cj.z, V), lane_u32(cj.w, V));
+                    have_c4 = true;
+                  }
+                }
+              }
+              if (have_c4) {
+                // (c4 is x's expansion)
+              } else if (!was_hit) {
                 // not among the lanes: the group lives in another bucket (the minimizer changed), in a
                 // bucket too large for the lanes, or does not exist.  Its key is worked out once: the
                 // directory word of its bucket (kept in dcache) and, already on its way, its home pair.
                 PendingLookup p;
                 children_issue_wave(tab, x, &dcache, &p);
                 SlotHit h2;
-                h2.hit = false; h2.info = 0; h2.ntag = EMPTY;
+                h2.hit = false; h2.info = 0;
                 if (!bl.valid || p.g.bucket != bl.bucket) {
-                  bucket_load_wave(tab, rule, p.g.bucket, dcache.lo, dcache.hi, keys, cap, &bl, &fetch_u);
+                  bucket_load_wave(tab, rule, p.g.bucket, dcache.lo, dcache.hi, node_hint, &bl, &fetch_u);
+                  KM_DC(dc_bload);
+                  KM_DT(dt_bload);
 #ifdef KM_DFS_STAMPS
                   ++dfs_loads;
                   if (bl.S > dfs_maxS) dfs_maxS = bl.S;
@@ -895,8 +1092,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                   c = h2.info & 3u;
                   cnt = h2.info >> 16;
                   hint = (h2.info & SLOT_HINT) != 0;
-                  T = h2.ntag;
                   child = ((x << 2) | c) & tab.kmask;
+                  T = tag_of_suffix(child);
                   return true;
                 }
                 if (!h2.hit) {
@@ -940,7 +1137,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 KM_DFS_STAMP(0);
                 // ---- the expansion of x: its group among the slots the lanes hold
                 SlotHit h;
-                h.hit = false; h.info = 0; h.ntag = EMPTY;
+                h.hit = false; h.info = 0;
                 if (bl.resident) h = bucket_find_wave(bl, T);   // (resident implies valid)
 #ifdef KM_DFS_STAMPS
                 if (h.hit) asm volatile("" :: "s"(h.info));
@@ -950,8 +1147,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 c = h.info & 3u;
                 cnt = h.info >> 16;
                 hint = (h.info & SLOT_HINT) != 0;
-                T = h.ntag;
                 child = ((x << 2) | c) & tab.kmask;
+                T = tag_of_suffix(child);
               }
               if (stop) break;
               if (!step_slow(was_hit)) break;
@@ -965,6 +1162,8 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             const uint64_t x_end = x;
             if (n) {
               steps += n;
+              KM_DC(dc_runs); KM_DCN(dc_steps, n);
+              KM_DT0();
 #ifdef KM_DFS_STAMPS
               dfs_steps += n;
               ++dfs_runs;
@@ -975,8 +1174,12 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               int slot = -1;
               uint32_t st8 = 0;
               if (act) {
-                slot = set_lookup_lane<2>(keys, cap, rkey, &found);
-                if (found) st8 = meta_state(state[slot]);
+                if (ref_index(rkey) != NO_NODE) {            // a k-mer of the target: a node
+                  found = true; st8 = ST_NODE; slot = 0;
+                } else {
+                  slot = set_lookup_lane<2>(keys, cap, rkey, &found);
+                  if (found) st8 = meta_state(state[slot]);
+                }
               }
               bool stop = act && (slot < 0 || (found && (st8 == ST_NODE || st8 == ST_ONSTACK)));
               // ... or repeats an earlier child of the run (a loop).  Every child of a run is a
@@ -1027,11 +1230,13 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 pend.valid = false;
               }
               step_sync();
+              KM_DT(dt_book);
               KM_DFS_STAMP(7);                             // booking of a run
             }
           }
           if (mask == 0) {
             if (bsp == 0) break;                         // DFS from this seed is done
+            KM_DT0();
             --bsp;
             mem_sync();
             const BranchFrame f = bf[bsp];
@@ -1044,17 +1249,25 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             cur = fk[depth - 1];
             c4 = f.c4; mask = f.mask; brk = f.brk;
             step_sync();
+            KM_DT(dt_unwind);
             KM_DFS_STAMP(4);                               // unwind to a branch frame
             continue;
           }
+          KM_DT0();
           const uint32_t c = (uint32_t)__ffs((int)mask) - 1;
           mask &= mask - 1;
           const uint64_t child = ((cur << 2) | c) & tab.kmask;
           const uint32_t ccnt = pick4(c4, c);
           bool found;
-          int slot = set_find<2>(keys, cap, child, &found);
-          if (slot < 0) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
-          const uint32_t stt = found ? meta_state(state[slot]) : 0u;
+          int slot = 0;
+          uint32_t stt;
+          if (__builtin_amdgcn_readfirstlane((int)(ref_index(child) != NO_NODE))) {   // a k-mer of the target: a node
+            found = true; stt = ST_NODE;
+          } else {
+            slot = set_find<2>(keys, cap, child, &found);
+            if (slot < 0) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
+            stt = found ? meta_state(state[slot]) : 0u;
+          }
           KM_DFS_STAMP(5);                                 // node-set probe of the child
           if (found && (stt == ST_NODE || stt == ST_ONSTACK)) {
             // rejoin (or loop): for p in stack: node_data[p] = jf.query(p)
@@ -1073,6 +1286,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               reg = depth;
               step_sync();
             }
+            KM_DT(dt_rejoin);
             KM_DFS_STAMP(6);                               // rejoin: register the stack
           } else if (depth + 1 <= a.max_stack) {
             // __extend(stack + [child], breaks)
@@ -1084,11 +1298,12 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
               bool wn;
               for (uint32_t j = lane; j < n_nodes; j += 64) {
                 const uint64_t kk = (j < n_ref) ? kmer_at(j) : a.node_kmer[nb + j];
+                if (j < n_ref && (uint32_t)pos[pos_home((uint32_t)(kk >> 2))] == j) continue;   // it owns its slot of the position table
                 const int s2 = set_insert_lane<2>(keys, cap, kk, &wn);
                 if (s2 >= 0) state[s2] = slot_meta(ST_NODE, j);
               }
               __syncthreads();
-              for (uint32_t j = lane; j < depth; j += 64) {
+              for (uint32_t j = 1 + lane; j < depth; j += 64) {       // (frame 0 is the seed: a node)
                 const int s2 = set_insert_lane<2>(keys, cap, fk[j], &wn);
                 if (s2 >= 0) {
                   if (wn) state[s2] = slot_meta(ST_ONSTACK, 0);
@@ -1096,7 +1311,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
                 }
               }
               __syncthreads();
-              set_count = n_nodes + (depth - reg);
+              set_count = n_losers + (n_nodes - n_ref) + (depth - reg);
               if (set_count + 1 > set_limit) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
               slot = set_find<2>(keys, cap, child, &found);
               if (slot < 0 || found) { st = T_INTERNAL; break; }
@@ -1122,6 +1337,7 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
             cur = child;
             need_expand = true;
             step_sync();
+            KM_DT(dt_rejoin);
             KM_DFS_STAMP(7);                               // push
           }
           // else: the child's __extend returns at once (len(stack) > max_stack)
@@ -1172,6 +1388,14 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
       // them.  They all sit in the probe sequence that starts at P's home slot.
       auto nodes_with_prefix = [&](uint64_t P, uint32_t self, uint32_t* one, uint32_t* first = nullptr) -> uint32_t {
         uint32_t cnt = 0, sl = set_home(P, cap);
+        {                                                    // the target k-mer that owns P's slot of the position table
+          const uint32_t w = (uint32_t)pos[pos_home((uint32_t)P)];
+          if (w != POS_NONE && w != self && (kmer_at(w) >> 2) == P) {
+            if (first) *first = w;
+            cnt = 1;
+            *one = w;
+          }
+        }
         for (uint32_t step = 0; step < cap; ++step) {
           const uint64_t kv = keys[sl];
           if (kv == EMPTY) break;
@@ -1440,6 +1664,10 @@ __global__ __launch_bounds__(64) void k_dfs(WalkArgs a) {
   if (a.stamps && lane == 0) {
     unsigned long long* o = a.stamps + 32ull * blockIdx.x;
     o[0] = life0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = t; o[3] = n_nodes - n_ref; o[4] = life1; o[5] = life2; o[6] = 0; o[7] = lifeB; o[8] = lifeC;
+#ifdef KM_DFS_COUNTERS
+    o[19] = dt_spec; o[20] = dt_book; o[21] = dt_gen; o[22] = dt_bload; o[23] = dt_rejoin; o[24] = dt_unwind; o[25] = dt_align;
+    o[9] = dc_slow; o[10] = dc_spec; o[11] = dc_rec; o[12] = dc_bload; o[13] = dc_gen; o[14] = dc_runs; o[15] = dc_full; o[16] = dc_v0; o[17] = dc_steps; o[18] = dc_noalign;
+#endif
     o[31] = 0x6c6966655f646673ull;
   }
 #endif

@@ -250,10 +250,17 @@ def find_mutation_sharded(targets, db_path, analyse=None, load_records=None, par
             raise payload[1]
         return payload[1]
     bucket = [None] * world if rank == 0 else None
+    # whatever cannot be pickled (an exception holding a handle, say) is replaced by its text HERE, before
+    # the collective: exactly one gather_object per rank, never a second one after a failure inside the first
+    # (the ranks would then sit in different collectives)
+    import pickle
     try:
-        dist.gather_object(payload, bucket, dst=0)
-    except Exception:                          # an exception that does not pickle: send its text
-        dist.gather_object(("error", RuntimeError(repr(payload[1]))), bucket, dst=0)
+        pickle.dumps(payload)
+    except Exception:                          # noqa: BLE001
+        what = payload[1]
+        payload = ("error", RuntimeError("%s: %s" % (type(what).__name__, what) if isinstance(what, BaseException)
+                                         else "rank %d: result of analyse() cannot be pickled (%s)" % (rank, type(what).__name__)))
+    dist.gather_object(payload, bucket, dst=0)
     if rank != 0:
         return None
     out = [None] * len(targets)

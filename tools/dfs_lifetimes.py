@@ -6,6 +6,11 @@ import sys
 
 os.environ["KM_SEED_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+COUNTERS = bool(os.environ.get("DFS_COUNTERS"))
+if COUNTERS:                 # a build that also counts, per wave, what the walk did (walk_kernel.h: KM_DFS_COUNTERS)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _diag
+    _diag.build(["-DKM_DFS_COUNTERS"], tag="dfs_counters")
 import numpy as np  # noqa: E402
 
 from km_amd import lib as kmlib, synth  # noqa: E402
@@ -57,5 +62,25 @@ for lo, hi in ((0, 1), (1, 20), (20, 32), (32, 45), (45, 70), (70, 100), (100, 1
     if m.any():
         print("  %3d-%3d new nodes: %5d waves, walk p50 %.1f p90 %.1f max %.1f us, life p50 %.1f max %.1f" %
               (lo, hi - 1, m.sum(), *np.percentile(walk[m], [50, 90, 100]), np.median(life[m]), life[m].max()))
+if COUNTERS:
+    short = ["slow", "spec", "rec", "bload", "gen", "runs", "full", "v0", "steps", "noalign"]
+    names = ["slow steps", "speculation rounds", "children recorded by them", "bucket loads", "general expansions", "runs",
+             "rounds that reached the target", "rounds with no step standing", "chain steps", "slow steps without an alignment"]
+    c = rec[:, 9:19].astype(np.float64)
+    print("per wave (mean / p50 / max):")
+    for j, nm in enumerate(names):
+        print("  %-36s %6.2f %5.0f %5.0f" % (nm, c[:, j].mean(), np.median(c[:, j]), c[:, j].max()))
+    for lo, hi in ((20, 32), (32, 45), (45, 70)):
+        m = (nodes >= lo) & (nodes < hi)
+        if m.any():
+            print("  %d-%d new nodes:" % (lo, hi - 1), ", ".join("%s %.2f" % (short[j], c[m, j].mean()) for j in range(len(short))))
+    tn = ["speculation rounds", "booking", "general expansions", "bucket loads", "general child step (rejoin / push)", "unwinding", "alignment search"]
+    tt = rec[:, 19:26].astype(np.float64) / 100.0
+    print("time per wave in (us, mean / p50 / max):")
+    for j, nm in enumerate(tn):
+        print("  %-36s %6.2f %6.2f %6.2f" % (nm, tt[:, j].mean(), np.median(tt[:, j]), tt[:, j].max()))
+    print("  accounted for: %.1f of a mean walk of %.1f us" % (tt.sum(axis=1).mean(), walk.mean()))
+    for i in order[:4]:
+        print("  target %d:" % rec[i, 2], dict(zip(short, rec[i, 9:19].tolist())))
 b.close()
 db.close()
