@@ -47,6 +47,7 @@ enum {
   OT_OFF_COUNT, OT_OFF_EXTRA, OT_OFF_PLEN, OT_OFF_PMIN, OT_OFF_RUNOFF, OT_OFF_RSTART, OT_OFF_RLEN,
   OT_PROBES, OT_FETCHES, OT_SEED_PROBES, OT_N_FLAGGED, OT_SERIAL,
   OT_N_ESC = 24,        // 16-bit counts: counts >= 65535 met so far (k_out_scan zeroes it, k_out_pack adds)
+  OT_N_BIG_DEV = 25,    // targets the device's own large tier took in this run (walk_kernel.h: WalkArgs::big_ctl)
   OT_WORDS = 32
 };
 constexpr uint32_t OUT_ESC_CAP = 2048;   // exact counts the escape list of one delivery holds
@@ -60,6 +61,8 @@ struct OutArgs {
   uint32_t count16;                    // node counts as 16-bit values + escape list
   uint32_t count_fetches;              // the run counted table slots read (KM_RUN_COUNT_FETCHES); else reported as 0
   unsigned long long serial;           // stamped into totals[OT_SERIAL]: which run this delivery belongs to
+  const uint32_t* big_ctl;             // [0] targets handed to the device's large-tier walk, [1] to its graph pass (null: tier off)
+  uint32_t big_slots;
   // walk / graph results
   const uint32_t* status;
   const uint32_t* g_status;
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
     T[OT_N_FLAGGED] = *a.n_flagged;
     T[OT_SERIAL] = a.serial;
     for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) if (q != OT_N_ESC) T[q] = 0;
+    if (a.big_ctl) { const uint32_t w_ = min(a.big_ctl[0], a.big_slots), g_ = min(a.big_ctl[1], a.big_slots); T[OT_N_BIG_DEV] = w_ > g_ ? w_ : g_; }
     a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
   }
   if (nh) return;                        // the host finishes the batch and delivers again

@@ -77,6 +77,13 @@ struct GraphArgs {
   // part of the list is `left` (work_n[2] entries: what it could not answer) instead of all flagged ones.
   const uint32_t* left;
   uint32_t dfs_answers;      // 1: this run's k_dfs had its epilogue on
+  // large tier on the device (walk_kernel.h: WalkArgs::big_ctl): the LDS tier appends what it cannot hold to
+  // big_graph (count in big_ctl[1]); the large-tier launch that follows in the same stream takes tids = big_graph
+  // and the count from tids_n
+  uint32_t* big_ctl;
+  uint32_t* big_graph;
+  uint32_t big_slots;
+  const uint32_t* tids_n;
   // outputs
   uint32_t* g_status;        // per target: T_OK / T_NEEDS_BIG / T_INTERNAL
   uint32_t* t_npaths;        // per target
@@ -256,6 +263,10 @@ template <bool BIG, int K>
 __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   uint32_t t_;
   if (BIG || a0.tids || !a0.work_list) {
+    if (a0.tids_n) {                                  // the device's own list: as many entries as were appended (at most big_slots)
+      const uint32_t n_l = min(*a0.tids_n, a0.big_slots);
+      if (blockIdx.x >= n_l) return;
+    }
     t_ = a0.tids ? a0.tids[blockIdx.x] : blockIdx.x;
   } else {
     const uint32_t n_first = a0.dfs_answers ? a0.work_n[2] : a0.work_n[0];
@@ -270,7 +281,10 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
     if (blockIdx.x == 0 && n_total > gridDim.x) {
       for (uint32_t e = gridDim.x + threadIdx.x; e < n_total; e += GRAPH_THREADS) {
         const uint32_t tt = entry(e);
-        if (a0.status[tt] == T_OK) { a0.g_status[tt] = T_NEEDS_BIG; a0.t_npaths[tt] = 0; a0.t_pathbase[tt] = 0; a0.t_nruns[tt] = 0; }
+        if (a0.status[tt] == T_OK) {
+          a0.g_status[tt] = T_NEEDS_BIG; a0.t_npaths[tt] = 0; a0.t_pathbase[tt] = 0; a0.t_nruns[tt] = 0;
+          if (a0.big_ctl) { const uint32_t at = atomicAdd(&a0.big_ctl[1], 1u); if (at < a0.big_slots) a0.big_graph[at] = tt; }
+        }
       }
     }
     if (blockIdx.x >= n_total) return;
@@ -278,6 +292,12 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   }
   const uint32_t t = t_;
   GraphArgs a = a0;
+  // (LDS tier) this target goes to the large tier: the device's own, if its list has room
+  auto hand_to_big = [&]() {
+    if constexpr (!BIG) {
+      if (a0.big_ctl) { const uint32_t at = atomicAdd(&a0.big_ctl[1], 1u); if (at < a0.big_slots) a0.big_graph[at] = t; }
+    }
+  };
   if constexpr (K != 0) {               // instantiated for one k: shifts and masks fold
     a.k = K;
     a.kmask = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   const uint32_t n = m + 2, src = m, snk = m + 1;
   const uint32_t ncap = a.ncap, hcap = a.hcap;
   if (n > ncap || (uint64_t)3 * n > (uint64_t)2 * hcap || (!BIG && n >= 0xFFFFu)) {
-    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+    if (tid == 0) { a.g_status[t] = (BIG && !a0.tids_n) ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; hand_to_big(); }
     return;
   }
   const uint64_t* nkx = a.node_kmer + nb;        // valid for indices >= n_ref only
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   const int k = a.k;
   const uint32_t nwords = (n_ref + (uint32_t)k - 1 + 31) >> 5;
   if (nwords + 1 > a.words_cap) {
-    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+    if (tid == 0) { a.g_status[t] = (BIG && !a0.tids_n) ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; hand_to_big(); }
     return;
   }
 
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   uint64_t own_x[MAXOWN];                // FUSED: their k-mers (2c' looks up the suffixes of the walk's nodes)
   if constexpr (FUSED) {
     if (m > MAXOWN * NT) {                 // cannot happen with the LDS tier's geometry
-      if (tid == 0) { a.g_status[t] = T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+      if (tid == 0) { a.g_status[t] = T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; hand_to_big(); }
       return;
     }
 #pragma unroll
@@ -999,7 +1019,7 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   __syncthreads();
   const uint32_t n_cand = scal[0];
   if (n_cand > ccap) {
-    if (tid == 0) { a.g_status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; }
+    if (tid == 0) { a.g_status[t] = (BIG && !a0.tids_n) ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; hand_to_big(); }
     return;
   }
 

@@ -743,6 +743,8 @@ constexpr uint32_t FAST_EXTRA = 160;          // walk-discovered nodes a fast-ti
 constexpr uint32_t FAST_LDS_LIMIT = 64 * 1024;
 constexpr uint32_t FAST_BCAP_MAX = 512;       // branch frames the fast tier keeps in LDS
 constexpr uint32_t FAST_FCAP_MAX = 4096;      // stack frames per target in the fast tier's scratch
+constexpr uint32_t BIG_DEV_SLOTS = 32;        // targets per run the device's own large tier takes (the rest: the host's)
+constexpr uint64_t BIG_DEV_MAX_BYTES = 1ull << 30;   // ... unless their node storage would exceed this (huge -n)
 
 // Region A of the delivery buffer (deliver_kernel.h): offsets from n_targets alone.
 struct OutLayout { uint64_t totals, status, n_ref, probes, node_off, extra_off, path_off, ref_max, esc_node, esc_value, a_bytes; };
@@ -844,6 +846,13 @@ struct km_batch {
   DevBuf<float> d_tref;               // shared reference-chain distances
   DevBuf<uint32_t> d_big_ids;
   DevBuf<unsigned char> d_big_ws;
+  // the device's own large tier (walk_kernel.h: WalkArgs::big_ctl)
+  DevBuf<uint64_t> d_node_base0;
+  DevBuf<uint32_t> d_big_ctl, d_big_walk, d_big_graph;
+  DevBuf<unsigned char> d_bigdev_walk_ws, d_bigdev_graph_ws;
+  uint32_t big_entry = 0;              // nodes per slot of the region (0: tier off)
+  uint64_t big_region = 0;             // its first node (the region sits in front of the fast-tier layout)
+  uint32_t n_big_dev = 0;              // targets it took in the last synchronised run
   // host mirrors after sync
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
   unsigned long long h_overflow = 0;
@@ -930,7 +939,17 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   if (rc == KM_OK && hipMemset(b->d_scan_ticket.p, 0, 4) != hipSuccess) rc = fail(KM_E_HIP, "hipMemset failed");
   A(b->d_probes.alloc(max_targets));
   A(b->d_fetches.alloc(max_targets));
-  const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA;
+  {
+    // the device's large tier: BIG_DEV_SLOTS slots of the reference's own bound on a walk (MutationFinder.py:140-156)
+    const uint64_t entry = (uint64_t)params->max_node + params->max_stack + 1;
+    if (!getenv("KM_BIG_DEVICE_OFF") && entry < 0x7FFFFFFFull && entry * BIG_DEV_SLOTS * 12 <= BIG_DEV_MAX_BYTES) b->big_entry = (uint32_t)entry;
+  }
+  const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA + (uint64_t)b->big_entry * BIG_DEV_SLOTS;
+  A(b->d_node_base0.alloc(max_targets));
+  A(b->d_big_ctl.alloc(8));
+  A(b->d_big_walk.alloc(BIG_DEV_SLOTS));
+  A(b->d_big_graph.alloc(BIG_DEV_SLOTS));
+  if (rc == KM_OK && hipMemset(b->d_big_ctl.p, 0, 32) != hipSuccess) rc = fail(KM_E_HIP, "hipMemset failed");
   A(b->d_node_kmer.alloc(pool));
   A(b->d_node_cnt.alloc(pool));
   A(b->d_counters.alloc(POOL_GROUPS * POOL_CTR_STRIDE + 16));
@@ -988,6 +1007,8 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_p_target.release(); b->d_p_runbase.release(); b->d_p_nruns.release(); b->d_p_len.release();
   b->d_p_mincov.release(); b->d_r_start.release(); b->d_r_len.release();
   b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release(); b->d_stamps.release();
+  b->d_node_base0.release(); b->d_big_ctl.release(); b->d_big_walk.release(); b->d_big_graph.release();
+  b->d_bigdev_walk_ws.release(); b->d_bigdev_graph_ws.release();
   for (int i = 0; i < 7; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   if (b->d_out) (void)hipFree(b->d_out);
   if (b->h_out) (void)hipHostFree(b->h_out);
@@ -1009,7 +1030,8 @@ static int layout_targets(km_batch* b, const uint64_t* offsets, uint32_t n) {
   b->h_item_off.assign(n + 1, 0);
   b->h_node_base.assign(n, 0);
   b->h_node_cap.assign(n, 0);
-  uint64_t pool = 0, total_ref = 0;
+  uint64_t pool = (uint64_t)b->big_entry * BIG_DEV_SLOTS, total_ref = 0;   // (the large tier's region comes first)
+  b->big_region = 0;
   uint32_t max_len = 0;
   for (uint32_t t = 0; t < n; ++t) {
     if (offsets[t + 1] < offsets[t]) return fail(KM_E_ARG, "offsets must be non-decreasing");
@@ -1062,6 +1084,7 @@ static int push_layout(km_batch* b, hipStream_t st) {
   HIPCHK(hipMemcpyAsync(b->d_fw_off.p, b->h_fw_off.data(), (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_item_off.p, b->h_item_off.data(), (uint64_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_node_base.p, b->h_node_base.data(), (uint64_t)n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_node_base0.p, b->h_node_base.data(), (uint64_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_node_cap.p, b->h_node_cap.data(), (uint64_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   b->ran_walk = b->ran_graph = false;
@@ -1127,6 +1150,13 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.node_cnt = b->d_node_cnt.p;
   a.node_base = b->d_node_base.p;
   a.node_cap = b->d_node_cap.p;
+  a.node_base0 = b->d_node_base0.p;
+  a.big_ctl = b->big_entry ? b->d_big_ctl.p : nullptr;
+  a.big_walk = b->d_big_walk.p;
+  a.big_slots = BIG_DEV_SLOTS;
+  a.big_entry = b->big_entry;
+  a.big_region = b->big_region;
+  a.big_prep = 0;
   a.n_nodes = b->d_n_nodes.p;
   a.n_ref = b->d_n_ref.p;
   a.status = b->d_status.p;
@@ -1148,6 +1178,10 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.work_n = b->d_nflagged.p;
   g.left = b->d_left.p;
   g.dfs_answers = 0;
+  g.big_ctl = b->big_entry ? b->d_big_ctl.p : nullptr;
+  g.big_graph = b->d_big_graph.p;
+  g.big_slots = BIG_DEV_SLOTS;
+  g.tids_n = nullptr;
   g.n_targets = b->n_targets;
   g.node_kmer = b->d_node_kmer.p;
   g.node_cnt = b->d_node_cnt.p;
@@ -1334,6 +1368,8 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean, bool count16 
   oa.count16 = count16 ? 1u : 0u;
   oa.count_fetches = b->count_fetches ? 1u : 0u;
   oa.serial = ++b->serial;
+  oa.big_ctl = b->big_entry ? b->d_big_ctl.p : nullptr;
+  oa.big_slots = BIG_DEV_SLOTS;
   oa.status = b->d_status.p; oa.g_status = b->d_gstatus.p; oa.n_nodes = b->d_n_nodes.p; oa.n_ref = b->d_n_ref.p;
   oa.t_npaths = b->d_npaths.p; oa.t_pathbase = b->d_pathbase.p; oa.t_nruns = b->d_t_nruns.p;
   oa.t_refmax = b->d_t_refmax.p;
@@ -1389,21 +1425,23 @@ static int enqueue_deliver(km_batch* b, hipStream_t st, bool lean, bool count16 
   return KM_OK;
 }
 
-// The large tier of an earlier run moved some targets to bigger node storage: back to the
-// layout of layout_targets (a step replays on the same targets start from the same state).
+// The large tier of an earlier run moved some targets to bigger node storage: back to the layout of
+// layout_targets (a step replayed on the same targets starts from the same state).  The device arrays are reset
+// by k_pack itself (node_base0); this is the host's mirror of them.
 static int restore_layout(km_batch* b, hipStream_t st) {
+  (void)st;
   if (!b->layout_moved) return KM_OK;
   drop_graph(b);
   b->h_node_base = b->h_node_base0;
   b->h_node_cap = b->h_node_cap0;
   b->node_pool_used = b->node_pool0;
-  HIPCHK(hipMemcpyAsync(b->d_node_base.p, b->h_node_base.data(), (uint64_t)b->n_targets * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(b->d_node_cap.p, b->h_node_cap.data(), (uint64_t)b->n_targets * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
   b->layout_moved = false;
   return KM_OK;
 }
 
+static int launch_big_walk_dev(km_batch* b, hipStream_t st);
+static int launch_big_graph_dev(km_batch* b, hipStream_t st);
+static int ensure_bigdev_ws(km_batch* b);
 static double host_now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -1433,7 +1471,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     b->synced = true;
     return want_deliver ? enqueue_deliver(b, st, want_lean, want_c16) : KM_OK;
   }
-  {
+  if (stages & KM_STAGE_WALK) {
     int rc = restore_layout(b, st);
     if (rc != KM_OK) return rc;
   }
@@ -1453,6 +1491,8 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   GraphArgs& ga = b->ga;
   {
     int rc = b->d_frames.alloc((uint64_t)b->n_targets * wa.f_stride);
+    if (rc != KM_OK) return rc;
+    rc = ensure_bigdev_ws(b);
     if (rc != KM_OK) return rc;
   }
   wa.f_ws = b->d_frames.p;
@@ -1507,8 +1547,16 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     launch_dfs();
     HIPCHK(hipGetLastError());
     if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
+    {
+      int rc = launch_big_walk_dev(b, st);
+      if (rc != KM_OK) return rc;
+    }
     launch_pure(b, st, ga);
     launch_graph(b, st, ga);
+    {
+      int rc = launch_big_graph_dev(b, st);
+      if (rc != KM_OK) return rc;
+    }
     HIPCHK(hipGetLastError());
     graph_launched = true;
     b->ran_walk = true;
@@ -1564,12 +1612,82 @@ static int pull_status(km_batch* b, hipStream_t st) {
   return KM_OK;
 }
 
+// Geometry of the large-tier walk (global-memory workspaces sized for the reference's own bound on a walk)
+static int big_walk_geometry(km_batch* b, WalkArgs& a) {
+  const int k = b->db->k;
+  const uint32_t max_nref = b->max_len >= (uint32_t)k ? b->max_len - k + 1 : 1;
+  const uint64_t max_nodes = std::max<uint64_t>(max_nref, (uint64_t)b->p.max_node + b->p.max_stack) + 1;
+  const uint64_t hs = 2 * (max_nodes + b->p.max_stack + 64);
+  if (hs > 0x7FFFFF00ull) return fail(KM_E_ARG, "node limit too large");
+  a.hs_cap = round_up((uint32_t)hs, 64);
+  a.pcap = walk_pcap(max_nref);
+  a.words_cap = words_cap_for(b->max_len);
+  a.fcap = round_up(b->p.max_stack + 2, 2);
+  a.bcap = b->p.max_break + 1;
+  a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap, a.pcap);
+  return KM_OK;
+}
+
+// Workspaces of the device's own large tier (allocated before a step is launched or captured; they grow with the
+// longest target of the batch)
+static int ensure_bigdev_ws(km_batch* b) {
+  if (!b->big_entry) return KM_OK;
+  WalkArgs a;
+  memset(&a, 0, sizeof a);
+  int rc = big_walk_geometry(b, a);
+  if (rc != KM_OK) return rc;
+  rc = b->d_bigdev_walk_ws.alloc((uint64_t)BIG_DEV_SLOTS * a.g_stride);
+  if (rc != KM_OK) return rc;
+  const uint32_t ncap = b->big_entry + 2, hcap = round_up(ncap + ncap / 2 + 1, 64);
+  return b->d_bigdev_graph_ws.alloc((uint64_t)BIG_DEV_SLOTS * graph_ws_bytes<uint32_t>(ncap, hcap, words_cap_for(b->max_len)));
+}
+
+// The device's own large tier, walk: one more launch behind the fast k_dfs, in its stream — BIG_DEV_SLOTS single-wave
+// blocks that leave at once unless the fast kernel appended targets to the list (WalkArgs::big_ctl).
+static int launch_big_walk_dev(km_batch* b, hipStream_t st) {
+  if (!b->big_entry) return KM_OK;
+  WalkArgs a;
+  fill_walk_args(b, a);
+  int rc = big_walk_geometry(b, a);
+  if (rc != KM_OK) return rc;
+  if (b->d_bigdev_walk_ws.n < (uint64_t)BIG_DEV_SLOTS * a.g_stride) return fail(KM_E_STATE, "large-tier workspace missing");
+  a.g_ws = b->d_bigdev_walk_ws.p;
+  a.list = b->d_big_walk.p;
+  a.n_list_dev = b->d_big_ctl.p;
+  a.n_list_host = 0;
+  a.big_prep = 1;
+  a.stamps = nullptr;
+  hipLaunchKernelGGL((k_dfs<true, 0>), dim3(BIG_DEV_SLOTS), dim3(64), 0, st, a);
+  return KM_OK;
+}
+// ... and graph: behind the fast k_graph, over what it (or the large-tier walk's results) could not hold
+static int launch_big_graph_dev(km_batch* b, hipStream_t st) {
+  if (!b->big_entry) return KM_OK;
+  GraphArgs g;
+  fill_graph_args(b, g);
+  g.ncap = b->big_entry + 2;
+  g.hcap = round_up(g.ncap + g.ncap / 2 + 1, 64);
+  g.words_cap = words_cap_for(b->max_len);
+  g.g_stride = graph_ws_bytes<uint32_t>(g.ncap, g.hcap, g.words_cap);
+  if (b->d_bigdev_graph_ws.n < (uint64_t)BIG_DEV_SLOTS * g.g_stride) return fail(KM_E_STATE, "large-tier workspace missing");
+  g.g_ws = b->d_bigdev_graph_ws.p;
+  g.tids = b->d_big_graph.p;
+  g.tids_n = b->d_big_ctl.p + 1;
+  hipLaunchKernelGGL((k_graph<true, 0>), dim3(BIG_DEV_SLOTS), dim3(GRAPH_THREADS), 0, st, g);
+  return KM_OK;
+}
+
 // Large tier: rerun the listed targets with global-memory workspaces.
 static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream_t st) {
   const uint32_t nb = (uint32_t)ids.size();
   const int k = b->db->k;
   drop_graph(b);                      // a captured step holds the addresses that change below
   b->layout_moved = true;
+  if (b->big_entry) {                 // the device's own large tier may have re-homed targets of this run
+    HIPCHK(hipMemcpyAsync(b->h_node_base.data(), b->d_node_base.p, (uint64_t)b->n_targets * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b->h_node_cap.data(), b->d_node_cap.p, (uint64_t)b->n_targets * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   // per-target node storage big enough for the reference's own bound
   uint64_t extra = 0;
   std::vector<uint64_t> old_base;
@@ -1609,19 +1727,12 @@ static int run_big_walk(km_batch* b, const std::vector<uint32_t>& ids, hipStream
   int rc = b->d_big_ids.alloc(nb); if (rc != KM_OK) return rc;
   HIPCHK(hipMemcpyAsync(b->d_big_ids.p, ids.data(), (uint64_t)nb * 4, hipMemcpyHostToDevice, st));
 
-  const uint32_t max_nref = b->max_len >= (uint32_t)k ? b->max_len - k + 1 : 1;
   WalkArgs a;
   fill_walk_args(b, a);
   a.n_list_dev = nullptr;
-  const uint64_t max_nodes = std::max<uint64_t>(max_nref, (uint64_t)b->p.max_node + b->p.max_stack) + 1;
-  const uint64_t hs = 2 * (max_nodes + b->p.max_stack + 64);
-  if (hs > 0x7FFFFF00ull) return fail(KM_E_ARG, "node limit too large");
-  a.hs_cap = round_up((uint32_t)hs, 64);
-  a.pcap = walk_pcap(max_nref);
-  a.words_cap = words_cap_for(b->max_len);
-  a.fcap = round_up(b->p.max_stack + 2, 2);
-  a.bcap = b->p.max_break + 1;
-  a.g_stride = walk_ws_bytes(a.hs_cap, a.words_cap, a.fcap, a.bcap, a.pcap);
+  a.big_ctl = nullptr;                // (this pass IS the fallback)
+  rc = big_walk_geometry(b, a);
+  if (rc != KM_OK) return rc;
   // run in slices so the workspace stays bounded
   const uint64_t budget = 8ull << 30;
   uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb, budget / a.g_stride));
@@ -1893,7 +2004,7 @@ static void sizes_of_result(const km_batch* b, km_batch_sizes_t* s) {
   s->n_extra = T[OT_N_EXTRA];
   s->logical_probes = T[OT_PROBES];
   s->table_fetches = T[OT_FETCHES];
-  s->n_big_tier = b->n_big;
+  s->n_big_tier = b->n_big + (uint32_t)T[OT_N_BIG_DEV];
   s->n_flagged = (uint32_t)T[OT_N_FLAGGED];
   s->seed_probes = T[OT_SEED_PROBES];
   s->n_count_escapes = b->count16 ? (uint32_t)T[OT_N_ESC] : 0;

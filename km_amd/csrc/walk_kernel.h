@@ -126,8 +126,19 @@ struct WalkArgs {
   // per-target outputs
   uint64_t* node_kmer;
   uint32_t* node_cnt;
-  const uint64_t* node_base;
-  const uint32_t* node_cap;
+  uint64_t* node_base;             // where a target's nodes live now (k_pack resets it to node_base0; the large tier re-homes a target)
+  uint32_t* node_cap;
+  const uint64_t* node_base0;      // the fast-tier layout (never changes between two km_batch_set_targets)
+  // large tier on the device: targets the fast kernels cannot hold are appended to big_walk (count in big_ctl[0]; k_graph's
+  // to big_graph, big_ctl[1]) and finished by a second launch in the same stream, a slot of `big_entry` nodes each in
+  // the region of the node pools that starts at big_region — no host round trip.  What does not fit there (more than
+  // big_slots targets, a target above big_entry) keeps T_NEEDS_BIG and is finished by the host as before.
+  uint32_t* big_ctl;
+  uint32_t* big_walk;
+  uint32_t big_slots;
+  uint32_t big_entry;
+  uint64_t big_region;
+  uint32_t big_prep;               // k_dfs<BIG>: this launch works off big_walk and re-homes its targets itself
   uint32_t* n_nodes;
   uint32_t* n_ref;
   uint32_t* status;
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
   const uint64_t L = a.toff[t + 1] - off;
   const uint64_t wo = a.woff[t];
   const uint64_t fwo = a.fw_off[t];
-  const uint64_t nbase = a.node_base[t];
+  const uint64_t nbase = a.node_base0[t];
   const uint64_t item0 = a.item_off[t];
   const uint32_t nwords = (uint32_t)((L + 31) >> 5);
   const uint32_t n_ref = (L >= (uint64_t)a.tab.k) ? (uint32_t)(L - a.tab.k + 1) : 0;
@@ -341,6 +352,9 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
     a.dfs_probes[t] = 0;
     a.fetches[t] = 0;
     a.tflag[t] = 0;
+    a.node_base[t] = nbase;                  // (a large-tier pass of the last run may have re-homed the target)
+    a.node_cap[t] = n_ref + a.fast_extra;
+    if (t == 0 && a.big_ctl) { a.big_ctl[0] = 0; a.big_ctl[1] = 0; }
     if (t == 0) { a.n_flagged[0] = 0; a.n_flagged[1] = 0; a.n_flagged[2] = 0; }   // [1]: targets k_graph_pure hands to k_graph, [2]: those k_dfs's epilogue leaves to it
   }
 }
@@ -606,11 +620,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   if constexpr (BIG) {
     const uint32_t n_list = a.n_list_dev ? *a.n_list_dev : a.n_list_host;
     if (blockIdx.x >= n_list) return;
+    if (a.big_prep && blockIdx.x >= a.big_slots) return;
     t = a.list[blockIdx.x];
     if (a.status[t] != T_OK && a.status[t] != T_NEEDS_BIG) return;
     n_ref = a.n_ref[t];
     nb = a.node_base[t];
     node_cap = a.node_cap[t];
+    if (a.big_prep) {
+      // the device's own large tier: slot blockIdx.x of the region; the seed kernel's counts move there
+      const uint64_t need = (uint64_t)max(n_ref, a.max_node + a.max_stack) + 1;
+      if (need > (uint64_t)a.big_entry || a.status[t] != T_NEEDS_BIG) return;          // (left to the host)
+      const uint64_t nb_new = a.big_region + (uint64_t)blockIdx.x * a.big_entry;
+      for (uint32_t j = lane; j < n_ref; j += 64) a.node_cnt[nb_new + j] = a.node_cnt[nb + j];
+      if (lane == 0) { a.node_base[t] = nb_new; a.node_cap[t] = a.big_entry; }
+      nb = nb_new;
+      node_cap = a.big_entry;
+      __syncthreads();
+    }
     wo = a.woff[t];
     fwo = a.fw_off[t];
   } else {
@@ -670,8 +696,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   if (nwords + 1 > a.words_cap || n_ref > node_cap || (uint64_t)n_ref * 4 > (uint64_t)pcap * 3 || n_ref >= POS_NONE) {
     if (lane == 0) {
       a.status[t] = BIG ? T_INTERNAL : T_NEEDS_BIG;
-      // (with the epilogue on, a flagged target's t_refmax is this kernel's to write: k_graph_pure leaves it alone)
-      if constexpr (!BIG) { if (a.epi != nullptr) a.epi->t_refmax[t] = NOT_BARE; }
+      if constexpr (!BIG) {
+        // (with the epilogue on, a flagged target's t_refmax is this kernel's to write — k_graph_pure leaves it
+        // alone — and k_graph finds the target through the list of what the epilogue left)
+        if (a.epi != nullptr) { a.epi->t_refmax[t] = NOT_BARE; a.epi->left[atomicAdd(a.epi->n_left, 1u)] = t; }
+        if (a.big_ctl) { const uint32_t at = atomicAdd(&a.big_ctl[0], 1u); if (at < a.big_slots) a.big_walk[at] = t; }
+      }
     }
     return;
   }
@@ -891,8 +921,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             KM_DFS_STAMP(8);                               // thresholds
             // the walk most likely continues with the first kept child: request its lookup
             // now, its latency overlaps the bookkeeping of this step
-            if (mask && depth + 1 <= a.max_stack) {
-              children_issue_wave(tab, ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask, &dcache, &pend);
+            // (unless that child is a k-mer of the target — for a seed it mostly is, its successor on the target: a
+            // rejoin, never expanded; the chain that follows is looked up by the run's own means)
+            const uint64_t first_child = ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask;
+            if (mask && depth + 1 <= a.max_stack &&
+                !__builtin_amdgcn_readfirstlane((int)(ref_index(first_child) != NO_NODE))) {
+              children_issue_wave(tab, first_child, &dcache, &pend);
 #ifdef KM_DFS_STAMPS
               dfs_acc[9] += (uint32_t)pend.t_key - dfs_prev;   // key of the next lookup
               dfs_prev = (uint32_t)pend.t_key;
@@ -1214,7 +1248,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                   ++brk;
                   if (brk > a.max_break) mask = 0;
                 }
-                if (mask && depth + 1 <= a.max_stack) {        // the general step continues: request its lookup
+                if (mask && depth + 1 <= a.max_stack && !(hint && !expanded)) {   // the general step continues: request its lookup (not for a child that is about to rejoin)
                   const uint64_t next = ((cur << 2) | ((uint32_t)__ffs((int)mask) - 1)) & tab.kmask;
                   if (!(pend.valid && pend.X == next)) children_issue_wave(tab, next, &dcache, &pend);
                 }
@@ -1673,6 +1707,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
 #endif
   if (lane == 0) {
     a.status[t] = st;
+    if constexpr (!BIG) {
+      if (st == T_NEEDS_BIG && a.big_ctl) { const uint32_t at = atomicAdd(&a.big_ctl[0], 1u); if (at < a.big_slots) a.big_walk[at] = t; }
+    }
     if (st != T_NEEDS_BIG) {     // a large-tier rerun restarts from the seed kernel's counters
       a.n_nodes[t] = n_nodes;
       a.dfs_probes[t] = probes_u;
