@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   if (a.stamps) life0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef KM_DFS_COUNTERS
+  uint32_t dc_nonres = 0, dt_nonres = 0, dc_bigS = 0;
   uint32_t dc_slow = 0, dc_spec = 0, dc_rec = 0, dc_bload = 0, dc_gen = 0, dc_runs = 0, dc_full = 0, dc_v0 = 0, dc_steps = 0, dc_noalign = 0;
   uint32_t dt_spec = 0, dt_book = 0, dt_gen = 0, dt_bload = 0, dt_rejoin = 0, dt_unwind = 0, dt_align = 0, dt_t0 = 0;   // 10 ns units
 #define KM_DC(x) (++(x))
@@ -1004,14 +1005,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                 // the k-mer at stack position s is the seed (target k-mer i) shifted by s bases: x, at position
                 // depth - 1 + n, ends at target position i + k - 1 + that if the walk has not shifted against the
                 // target — at the first k-mer off the target that is the hypothesis, later on x's last bases say
-                {
-                  const uint32_t sx = depth - 1 + n, e_sub = i + (uint32_t)k + sx;
+                // (only near the seed: further on, x's last SPEC_ELL bases are looked for anywhere in the target, (b))
+                const uint32_t sx = depth - 1 + n;
+                if (sx <= 4 || !spec_ell_ok) {
+                  const uint32_t e_sub = i + (uint32_t)k + sx;
                   if (e_sub < Lb && e_sub >= (uint32_t)k) {
                     const uint64_t d = x ^ kmer_at(e_sub - (uint32_t)k);
                     const uint32_t agree = d ? ((uint32_t)__ffsll((long long)d) - 1) >> 1 : (uint32_t)k;
                     // (the seed's other child — the k-mer at stack position 1 — ends on the substituted base: the
                     // bases behind it agree, that one does not)
-                    if ((sx <= 4 && agree == sx - 1) || agree >= 4) e = e_sub;
+                    if ((sx <= 4 && agree == sx - 1) || agree >= SPEC_ELL) e = e_sub;
                   }
                 }
                 if (e == SPEC_NONE && spec_ell_ok) {
@@ -1135,6 +1138,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                   if (!bl.resident) ++dfs_nonres;
 #endif
                   c4 = children_finish_wave(tab, p, &fetch_u);   // (all zero if the group does not exist)
+                  KM_DC(dc_nonres); KM_DT(dt_nonres);
+#ifdef KM_DFS_COUNTERS
+                  if (bl.S > dc_bigS) dc_bigS = bl.S;
+#endif
                   KM_DFS_STAMP(12);                        // chain: lookup in a bucket too large for the lanes
                 } else {
                   c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
@@ -1700,6 +1707,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
     o[0] = life0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = t; o[3] = n_nodes - n_ref; o[4] = life1; o[5] = life2; o[6] = 0; o[7] = lifeB; o[8] = lifeC;
 #ifdef KM_DFS_COUNTERS
     o[19] = dt_spec; o[20] = dt_book; o[21] = dt_gen; o[22] = dt_bload; o[23] = dt_rejoin; o[24] = dt_unwind; o[25] = dt_align;
+    o[26] = dc_nonres; o[27] = dt_nonres; o[28] = dc_bigS;
     o[9] = dc_slow; o[10] = dc_spec; o[11] = dc_rec; o[12] = dc_bload; o[13] = dc_gen; o[14] = dc_runs; o[15] = dc_full; o[16] = dc_v0; o[17] = dc_steps; o[18] = dc_noalign;
 #endif
     o[31] = 0x6c6966655f646673ull;

@@ -80,7 +80,11 @@ if COUNTERS:
     for j, nm in enumerate(tn):
         print("  %-36s %6.2f %6.2f %6.2f" % (nm, tt[:, j].mean(), np.median(tt[:, j]), tt[:, j].max()))
     print("  accounted for: %.1f of a mean walk of %.1f us" % (tt.sum(axis=1).mean(), walk.mean()))
-    for i in order[:4]:
-        print("  target %d:" % rec[i, 2], dict(zip(short, rec[i, 9:19].tolist())))
+    print("  non-resident lookups per wave: mean %.2f max %d, %.2f us each; largest bucket met by one: %d slots" %
+          (rec[:, 26].mean(), rec[:, 26].max(), rec[:, 27].sum() / 100.0 / max(1, rec[:, 26].sum()), rec[:, 28].max()))
+    for i in order[:6]:
+        print("    (non-resident lookups %d, %.1f us, largest bucket %d)" % (rec[i, 26], rec[i, 27] / 100.0, rec[i, 28]))
+        print("  target %d: walk %.1f us:" % (rec[i, 2], walk[i]), dict(zip(short, rec[i, 9:19].tolist())),
+              {nm.split()[0]: round(float(v), 1) for nm, v in zip(tn, tt[i])})
 b.close()
 db.close()
