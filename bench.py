@@ -239,7 +239,7 @@ def oracle_check(case, views, set_ids, T, n_check):
             "oracle_keys": int(len(case["keys"])), "oracle_build_s": t_build}
 
 
-def hard_workload(args, case, dev_index, stream, T, n_fl):
+def hard_workload(args, case, dev_index, stream, T, n_fl, profile_only=False):
     """BASELINE config 4's shape made hard (example/run_leucegene.sh:13-35 is what real catalogs
     look like): 85 % of the targets carry 1-3 variants of every kind (15 % of them homozygous), 3 % of the
     k-mers an above-threshold dead-end branch, 3 % sub-threshold noise, and 4 % of the variant targets 3-5
@@ -276,6 +276,26 @@ def hard_workload(args, case, dev_index, stream, T, n_fl):
         batches.append(bq)
     stages = kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH
     deliver = stages | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN | kmlib.KM_DELIVER_COUNT16
+    if profile_only:
+        # every launch: one kernel alone (KM_RUN_SERIAL) over one of the two target sets, never the one before
+        tm = []
+        for i in range(args.warmup + args.steps):
+            bq, sq = batches[i % n_fl], streams[i % n_fl]
+            bq.run(deliver | kmlib.KM_RUN_TIMED | kmlib.KM_RUN_SERIAL, sq)
+            sz = bq.wait_result()
+            if i >= args.warmup:
+                tm.append(bq.timings())
+        tm = np.mean(np.array(tm), axis=0)
+        probes = float(sz.logical_probes)
+        out = {"steps": args.steps, "table_keys": int(len(keys)), "logical_probes_per_step": probes,
+               "kernel_ms": {"walk": float(tm[0]), "k_pack": float(tm[4]), "k_seed": float(tm[3]), "k_dfs": float(tm[5]),
+                             "graph": float(tm[1]), "deliver_kernels": float(tm[6]), "d2h_copy": float(tm[7])},
+               "walk_stage_frac_of_hbm_peak": probes * BYTES_PER_PROBE / (float(tm[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "targets_flagged": int(sz.n_flagged), "targets_in_large_tier": int(sz.n_big_tier)}
+        for bq in batches:
+            bq.close()
+        db.close()
+        return out
     kmlib.pump(batches, streams, max(n_fl, args.warmup), deliver)
     dts = []
     for _ in range(max(1, args.repeats)):
@@ -423,6 +443,14 @@ def main():
                     help="skip the second workload (config4_hard: several variants per target, branch noise, large-tier walks)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="how often the timed region (exactly --steps steps) is repeated; value = the median")
+    ap.add_argument("--one-at-a-time", action="store_true",
+                    help="run the batches strictly one after the other (run, wait for the delivery, next batch), still rotating "
+                         "over the --inflight distinct target sets: with --serial every launch of a profile is then a kernel "
+                         "alone on the GPU over a target set that was not the previous launch's (nothing replayed out of the "
+                         "256 MiB Infinity Cache) — the command behind profiles/*kernel_stats.csv and the PMC passes")
+    ap.add_argument("--profile-hard", action="store_true",
+                    help="only the second workload (config4_hard), one batch at a time, every kernel alone, rotating over its "
+                         "two target sets; prints its object and exits (the program behind profiles/*hard*)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batch workspaces in flight on separate HIP streams (software pipelining)")
     args = ap.parse_args()
@@ -507,6 +535,11 @@ def main():
         ranks_seen["world_size"] = int(dist.get_world_size())
     ranks_seen["hip_runtime"] = kmlib.HIP_RUNTIME_BOUND
 
+    if args.profile_hard:
+        hard = hard_workload(args, case, local_rank, None, T, n_fl, profile_only=True)
+        print(json.dumps({"config4_hard_profile": hard}), flush=True)
+        sys.exit(0)
+
     # ---- table: records to HBM (N > 1: ONE broadcast over RCCL), local build on every GPU --------------
     t_up = time.perf_counter()
     if use_torch:
@@ -579,6 +612,16 @@ def main():
         The loop itself runs inside the library (km_batch_pump) unless --py-loop: with the
         interpreter between a wait and the next launch a launch costs ~200 us of host time
         instead of ~50 (tools/launch_cost.py) and the GPU runs dry."""
+        if args.one_at_a_time:
+            for i in range(n_steps):
+                q = i % n_fl
+                batches[q].run(flags, tstreams[q])
+                if wait:
+                    batches[q].wait_result()
+                else:
+                    batches[q].sync()
+            device_sync()
+            return
         if wait and not args.py_loop:
             kmlib.pump(batches, tstreams, n_steps, flags)
             device_sync()
@@ -714,6 +757,38 @@ def main():
                   "value": Ts * world / (dt_strong / args.steps), "unit": "targets/s", "scaling": "strong"}
         for q in range(n_fl):
             batches[q].set_targets_dev(bases_all[set_ids[q] * T:(set_ids[q] + 1) * T].data_ptr(), offsets, stream)
+
+    # ---- what one GPU does with 1/2, 1/4, 1/8 of config 4's targets per step: the ceiling of config4_strong
+    # (the same 10 000 targets sharded over N GPUs) — measured here because 8-GPU nodes are the driver's to use
+    strong_ceiling = None
+    if rank == 0 and world == 1 and not args.only_step and not use_torch:
+        strong_ceiling = {"targets_total": T, "ms_per_step_all_targets_one_gpu": dt / args.steps * 1e3, "per_gpu_share": []}
+        for parts in (2, 4, 8):
+            Ts = T // parts
+            offs_s = (np.arange(Ts + 1, dtype=np.uint64) * np.uint64(args.length))
+            for q in range(n_fl):
+                batches[q].set_targets_packed(bases_host[set_ids[q] * T:set_ids[q] * T + Ts].reshape(-1), offs_s)
+            pipeline(2 * n_fl, deliver, True)
+            dts_s = [timed(deliver, True) for _ in range(3)]
+            ms_s = float(np.median(dts_s)) / args.steps * 1e3
+            # one batch alone (what a rank that has nothing else in flight would see)
+            lat = []
+            for i in range(8):
+                t_l = time.perf_counter()
+                batches[i % n_fl].run(deliver, tstreams[i % n_fl])
+                batches[i % n_fl].wait_result()
+                lat.append((time.perf_counter() - t_l) * 1e3)
+            strong_ceiling["per_gpu_share"].append(
+                {"n_gpus": parts, "targets_per_gpu": Ts, "ms_per_step_pipelined": ms_s, "ms_one_batch_alone": float(np.median(lat[2:])),
+                 "implied_value_at_n_gpus": T / (ms_s * 1e-3),
+                 "implied_speedup_vs_1_gpu": (dt / args.steps * 1e3) / ms_s})
+        for q in range(n_fl):
+            batches[q].set_targets_packed(bases_host[set_ids[q] * T:(set_ids[q] + 1) * T].reshape(-1), offsets)
+        pipeline(n_fl, deliver, True)
+        strong_ceiling["note"] = ("one GPU, 4 batches in flight of T/N targets each, results delivered: what every rank of config4_strong "
+                                  "would do per step if the N GPUs scaled perfectly; implied_speedup is the CEILING of the N-GPU "
+                                  "curve for BASELINE config 4 proper (10 000 targets per step in all), set by the per-step latency "
+                                  "floor of the kernels, not by any collective")
 
     # ---- a hard workload beside the headline one ------------------------------------------------------
     hard = None
@@ -927,6 +1002,7 @@ def main():
             "oracle_check": check,
             "ranks_seen": ranks_seen,
             "config4_strong": strong,
+            "config4_strong_ceiling_measured_on_one_gpu": strong_ceiling,
             "config4_hard": hard,
             "config5_samples": cfg5,
             "end_to_end_host_path": e2e,

@@ -166,6 +166,17 @@ int kmjf_upload(kmjf_t* h, int device);
 int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_keys,
                             const uint32_t* d_counts, uint64_t n, void* stream);
 
+/* One database on several GPUs of this process (BASELINE config 4: targets sharded, table replicated; the
+ * read-only handle every target of km/tools/find_mutation.py:29,47-58 shares).  `h` holds host records
+ * (kmjf_open / kmjf_from_records).  They are uploaded to devices[0], cross the links ONCE as one RCCL
+ * broadcast of the 12-byte records (not of the 8.8x larger table), and every device builds its own table:
+ * replicas[0] = h (now uploaded on devices[0]), replicas[1..n-1] = new handles for devices[1..n-1]
+ * (kmjf_close each).  n == 1 is kmjf_upload.  RCCL is loaded when first needed (librccl.so.1), the library
+ * does not link against it; KM_E_HIP if it is missing or a collective fails, KM_E_ARG for n < 1, a null
+ * argument or a device named twice.  One process per GPU (torch.distributed, MPI): broadcast the records
+ * with the launcher's own collective and call kmjf_upload_from_device (km_amd/dist.py does). */
+int kmjf_broadcast(kmjf_t* h, const int* devices, int n, kmjf_t** replicas);
+
 /* ---- lookups: replace Jellyfish.query (km/utils/Jellyfish.py:47-53; also the
  *      loop of common.get_cov, km/utils/common.py:73-92) and
  *      Jellyfish.get_child (km/utils/Jellyfish.py:55-72) ---------------------- */

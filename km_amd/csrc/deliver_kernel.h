@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
     T[OT_N_FLAGGED] = *a.n_flagged;
     T[OT_SERIAL] = a.serial;
     for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) if (q != OT_N_ESC) T[q] = 0;
-    if (a.big_ctl) { const uint32_t w_ = min(a.big_ctl[0], a.big_slots), g_ = min(a.big_ctl[1], a.big_slots); T[OT_N_BIG_DEV] = w_ > g_ ? w_ : g_; }
+    if (a.big_ctl) T[OT_N_BIG_DEV] = min(a.big_ctl[0], a.big_slots);      // (walks; a target only its graph pass took is not counted, as on the host's path)
     a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
   }
   if (nh) return;                        // the host finishes the batch and delivers again

@@ -515,6 +515,126 @@ extern "C" int kmjf_upload(kmjf_t* h, int device) {
   return rc;
 }
 
+// ---- kmjf_broadcast: one process, several GPUs.  RCCL is looked up at run time (dlopen) so that the library
+// has no link-time dependency on it; only its types come from the header.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+const RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(api.lib, "ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.lib, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.lib, "ncclGroupEnd"));
+    api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(api.lib, "ncclBroadcast"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+  });
+  const bool ok = api.lib && api.CommInitAll && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Broadcast;
+  return ok ? &api : nullptr;
+}
+}  // namespace
+
+extern "C" int kmjf_broadcast(kmjf_t* h, const int* devices, int n, kmjf_t** replicas) {
+  if (!h || !devices || !replicas || n < 1) return fail(KM_E_ARG, "bad argument");
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (devices[i] == devices[j]) return fail(KM_E_ARG, "device %d named twice", devices[i]);
+  int n_dev = 0;
+  HIPCHK(hipGetDeviceCount(&n_dev));
+  for (int i = 0; i < n; ++i)
+    if (devices[i] < 0 || devices[i] >= n_dev) return fail(KM_E_ARG, "no device %d (this process sees %d)", devices[i], n_dev);
+  for (int i = 0; i < n; ++i) replicas[i] = nullptr;
+  if (n == 1) {
+    int rc = kmjf_upload(h, devices[0]);
+    if (rc == KM_OK) replicas[0] = h;
+    return rc;
+  }
+  const RcclApi* api = rccl_api();
+  if (!api) return fail(KM_E_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  const uint64_t cnt = h->keys.size();
+  const uint64_t bytes = cnt * 12;                     // keys, then counts: one buffer, one broadcast
+  std::vector<unsigned char*> buf(n, nullptr);
+  std::vector<hipStream_t> st(n, nullptr);
+  std::vector<ncclComm_t> comm(n, nullptr);
+  std::vector<kmjf_t*> made;
+  bool comms_up = false;
+  auto cleanup = [&]() {
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(devices[i]);
+      if (buf[i]) (void)hipFree(buf[i]);
+      if (st[i]) (void)hipStreamDestroy(st[i]);
+      if (comms_up && comm[i]) (void)api->CommDestroy(comm[i]);
+    }
+  };
+  auto bail = [&](int code, const char* what, const char* detail) {
+    cleanup();
+    for (kmjf_t* r : made) (void)kmjf_close(r);
+    for (int i = 0; i < n; ++i) replicas[i] = nullptr;
+    return fail(code, "%s: %s", what, detail);
+  };
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipSetDevice(devices[i]);
+    if (e == hipSuccess) e = hipMalloc((void**)&buf[i], bytes ? bytes : 16);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+    if (e != hipSuccess) return bail(KM_E_NOMEM, "record buffer", hipGetErrorString(e));
+  }
+  {
+    hipError_t e = hipSetDevice(devices[0]);
+    if (e == hipSuccess && cnt) e = hipMemcpy(buf[0], h->keys.data(), cnt * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && cnt) e = hipMemcpy(buf[0] + cnt * 8, h->counts.data(), cnt * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(KM_E_HIP, "record upload", hipGetErrorString(e));
+  }
+  ncclResult_t nr = api->CommInitAll(comm.data(), n, devices);
+  if (nr != ncclSuccess) return bail(KM_E_HIP, "ncclCommInitAll", api->GetErrorString ? api->GetErrorString(nr) : "failed");
+  comms_up = true;
+  if (bytes) {
+    nr = api->GroupStart();
+    for (int i = 0; i < n && nr == ncclSuccess; ++i) {
+      (void)hipSetDevice(devices[i]);
+      nr = api->Broadcast(buf[i], buf[i], bytes, ncclUint8, 0, comm[i], st[i]);
+    }
+    const ncclResult_t ne = api->GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return bail(KM_E_HIP, "ncclBroadcast", api->GetErrorString ? api->GetErrorString(nr) : "failed");
+  }
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipSetDevice(devices[i]);
+    if (e == hipSuccess) e = hipStreamSynchronize(st[i]);
+    if (e != hipSuccess) return bail(KM_E_HIP, "broadcast did not complete", hipGetErrorString(e));
+  }
+  // every device builds its own table from its copy of the records
+  for (int i = 0; i < n; ++i) {
+    kmjf_t* r = h;
+    if (i > 0) {
+      int rc = kmjf_create(h->k, h->canonical, &r);
+      if (rc != KM_OK) return bail(rc, "replica", km_last_error());
+      made.push_back(r);
+    }
+    int rc = kmjf_upload_from_device(r, devices[i], reinterpret_cast<const uint64_t*>(buf[i]),
+                                     reinterpret_cast<const uint32_t*>(buf[i] + cnt * 8), cnt, st[i]);
+    if (rc != KM_OK) { const std::string why = km_last_error(); return bail(rc, "table build", why.c_str()); }
+    replicas[i] = r;
+  }
+  cleanup();
+  return KM_OK;
+}
+
 // Direct ingestion: header parsed on the host, the record area of the (memory-mapped) file is
 // copied to HBM as it is, unpacked there (k_unpack_records) and the table is built from the
 // device-resident records.  No host copy of the records is made or kept (kmjf_records()

@@ -116,7 +116,9 @@ def broadcast_records(keys, counts, k, canonical, device, src=0):
     else:
         meta = torch.zeros(3, dtype=torch.int64)
     meta = meta.to(device)
-    if world > 1:
+    # (a process group of ONE rank still issues the collectives: the RCCL path then runs on a one-GPU box as well)
+    collective = dist.is_initialized()
+    if collective:
         dist.broadcast(meta, src)
     n, k, canonical = (int(x) for x in meta.tolist())
     n_words = n + (n + 1) // 2                      # n keys, then n counts two to a 64-bit word
@@ -127,7 +129,7 @@ def broadcast_records(keys, counts, k, canonical, device, src=0):
         buf = torch.from_numpy(host).to(device)
     else:
         buf = torch.empty(n_words, dtype=torch.int64, device=device)
-    if world > 1:
+    if collective:
         dist.broadcast(buf, src)
     d_keys = buf[:n]
     d_cnts = buf[n:].view(torch.int32)[:n]

@@ -27,7 +27,7 @@ T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 # every symbol include/kmgpu.h declares (tests check the library exports them all)
 SYMBOLS = [
     "kmjf_open", "kmjf_load", "kmjf_from_records", "kmjf_create", "kmjf_close", "kmjf_info", "kmjf_records",
-    "kmjf_upload", "kmjf_upload_from_device", "kmjf_query_batch", "kmjf_children_batch",
+    "kmjf_upload", "kmjf_upload_from_device", "kmjf_broadcast", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
     "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_pump", "km_batch_debug_stamps", "km_batch_debug_counts",
@@ -175,6 +175,7 @@ def load():
         "kmjf_records": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "kmjf_upload": [vp, i32],
         "kmjf_upload_from_device": [vp, i32, vp, vp, u64, vp],
+        "kmjf_broadcast": [vp, C.POINTER(i32), i32, C.POINTER(vp)],
         "kmjf_query_batch": [vp, vp, u64, vp],
         "kmjf_children_batch": [vp, vp, u64, dbl, i64, i32, vp, vp],
         "kmjf_query_batch_dev": [vp, vp, u64, vp, vp],
@@ -345,6 +346,16 @@ class Database:
     def upload(self, device=0):
         check(self._lib.kmjf_upload(self._h, int(device)))
         return self
+
+    def broadcast(self, devices):
+        """One process, several GPUs (kmjf_broadcast): the host records go to devices[0], cross the links once as
+        one RCCL broadcast and every device builds its own table.  Returns one Database per device; the first is
+        this one."""
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        out = (C.c_void_p * max(1, len(devices)))()
+        check(self._lib.kmjf_broadcast(self._h, arr, len(devices), out))
+        return [self] + [Database(C.c_void_p(out[i])) for i in range(1, len(devices))]
 
     def upload_from_device(self, device, d_keys_ptr, d_counts_ptr, n, stream=None):
         check(self._lib.kmjf_upload_from_device(self._h, int(device), C.c_void_p(d_keys_ptr),

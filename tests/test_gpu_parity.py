@@ -1367,3 +1367,212 @@ def test_epilogue_of_k_dfs_answers_bubbles_and_changes_nothing(k, tmp_path):
     assert multi > 20                                                     # several bubbles per target were among them
     b.close()
     db.close()
+
+
+# ------------------------------------------------------------------ round 4
+_R4_FIELDS = ("status", "n_ref", "probes", "node_off", "node_kmer", "node_count", "path_off", "run_off", "run_start",
+              "run_len", "path_len", "path_min_cov")
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_speculation_along_the_target_changes_nothing(k, tmp_path):
+    """k_dfs looks a chain up along the target, one predicted step per lane (walk_kernel.h: "speculation along the
+    target") instead of one lookup after the other.  Lookups have no side effects: the same batch with the
+    speculation on (this process) and off (KM_SPECULATE=0 in a child process) gives identical arrays — every kind
+    of variant, several per target, homozygous ones, dead-end branches, tight stack budgets — and a sample of it
+    matches the C oracle probe for probe."""
+    import subprocess
+    import sys
+    from oracle import c_oracle
+    spec = dict(n_targets=1500, length=320, k=k, n_keys=300_000, seed=7300 + k, variant_frac=0.9,
+                variants_per_target=(1, 3), kinds=("snv", "ins", "del", "dup"), hom_frac=0.2,
+                branch_noise_frac=0.03, noise_frac=0.02, cov=(50, 1500), exact_pad=False)
+    case = synth.make_case(**spec)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], k).upload(0)
+    b = kmlib.Batch(db, max_targets=len(case["targets"]), max_total_bases=case["targets"].size)
+    b.set_targets([km.decode(r) for r in case["targets"]])
+    b.run()
+    on = b.fetch()
+    out = str(tmp_path / "spec_off.npz")
+    subprocess.check_call([sys.executable, "-c", _EPI_CHILD % {"root": os.path.dirname(HERE), "spec": spec, "k": k, "out": out}],
+                          env=dict(os.environ, KM_SPECULATE="0"))
+    off = np.load(out)
+    for name in _R4_FIELDS:
+        assert np.array_equal(on[name], off[name]), name
+    co = c_oracle.COracle(case["keys"], case["counts"], k)
+    noff, poff = on["node_off"].astype(np.int64), on["path_off"].astype(np.int64)
+    walked = 0
+    for t in range(0, len(case["targets"]), 5):
+        want = co.analyse(case["targets"][t])
+        assert want["status"] == int(on["status"][t]) == 0
+        assert (on["node_kmer"][noff[t]:noff[t + 1]] == want["kmers"]).all(), t
+        assert (on["node_count"][noff[t]:noff[t + 1]] == want["counts"]).all(), t
+        assert int(on["probes"][t]) == want["probes"], t
+        got = [kmlib.expand_path(on, p).tolist() for p in range(poff[t], poff[t + 1])]
+        assert got == want["paths"], t
+        walked += len(want["kmers"]) > int(on["n_ref"][t])
+    assert walked > 150
+    # a stack budget that cuts the chains short of their rejoin: the speculation may not look past it
+    for steps in (3, 17, 40):
+        b2 = kmlib.Batch(db, max_stack=steps, max_targets=300, max_total_bases=300 * 320)
+        b2.set_targets([km.decode(r) for r in case["targets"][:300]])
+        b2.run()
+        r2 = b2.fetch()
+        n2, p2 = r2["node_off"].astype(np.int64), r2["path_off"].astype(np.int64)
+        for t in range(0, 300, 3):
+            want = co.analyse(case["targets"][t], max_stack=steps)
+            assert (r2["node_kmer"][n2[t]:n2[t + 1]] == want["kmers"]).all() and int(r2["probes"][t]) == want["probes"], (steps, t)
+        b2.close()
+    b.close()
+    db.close()
+
+
+def test_device_large_tier_takes_what_the_lds_tier_cannot_hold(tmp_path):
+    """Targets that outgrow the LDS tier are finished by a second launch in the batch's own stream (walk_kernel.h:
+    WalkArgs::big_ctl), without the host: 40 targets of 2.6 kb among ordinary ones — more than the 32 slots of the
+    device's tier, so the rest goes through the host's — all equal to the oracle; the same batch again (the layout
+    is reset by k_pack) and with the device tier switched off (KM_BIG_DEVICE_OFF=1 in a child process) gives the
+    same arrays."""
+    import subprocess
+    import sys
+    spec = dict(n_targets=40, length=2600, n_keys=120_000, seed=818, variant_frac=0.6, variants_per_target=(1, 2))
+    case = synth.make_case(**spec)
+    small = synth.make_case(n_targets=60, length=300, n_keys=30_000, seed=819, variant_frac=0.5)
+    keys = np.concatenate([case["keys"], small["keys"]])
+    counts = np.concatenate([case["counts"], small["counts"]])
+    keys, first = np.unique(keys, return_index=True)
+    counts = counts[first]
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    seqs = []
+    for i in range(60):
+        seqs.append(km.decode(small["targets"][i]))
+        if i < 40:
+            seqs.append(km.decode(case["targets"][i]))
+    b = kmlib.Batch(db, max_targets=len(seqs), max_total_bases=sum(len(s_) for s_ in seqs))
+    b.set_targets(seqs)
+    b.run()
+    r1 = b.fetch()
+    # (n_big_tier counts the large-tier WALKS — the ~24 long targets with a variant; all 40 need its graph pass)
+    assert (r1["status"] == 0).all() and int(r1["n_big_tier"]) >= 15
+    b.run()                                                      # replay: same targets, same storage
+    r2 = b.fetch()
+    for name in _R4_FIELDS:
+        assert np.array_equal(r1[name], r2[name]), name
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": 31, "canonical": True, "keys": keys, "counts": counts})
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    _compare_with_oracle(jf, cpu, [("t%d" % i, s_) for i, s_ in enumerate(seqs)][:30])
+    child = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from km_amd import lib as kmlib
+d = np.load(%(inp)r, allow_pickle=True)
+db = kmlib.Database.from_records(d["keys"], d["counts"], 31).upload(0)
+seqs = [str(x) for x in d["seqs"]]
+b = kmlib.Batch(db, max_targets=len(seqs), max_total_bases=sum(len(s_) for s_ in seqs))
+b.set_targets(seqs)
+b.run()
+r = b.fetch()
+np.savez(%(out)r, **{k_: v for k_, v in r.items() if isinstance(v, np.ndarray)})
+"""
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "host_tier.npz")
+    np.savez(inp, keys=keys, counts=counts, seqs=np.array(seqs))
+    subprocess.check_call([sys.executable, "-c", child % {"root": os.path.dirname(HERE), "inp": inp, "out": out}],
+                          env=dict(os.environ, KM_BIG_DEVICE_OFF="1"))
+    host = np.load(out)
+    for name in _R4_FIELDS:
+        assert np.array_equal(r1[name], host[name]), name
+    b.close()
+    db.close()
+
+
+def test_one_path_long_target_does_not_keep_a_stale_reference_maximum():
+    """A flagged target beyond the LDS tier with one path: what lean delivery says about it (ref_max_cov: the
+    maximum of its own counts, or NOT_BARE with the counts themselves) must be this run's, whatever an earlier batch
+    left in that target's slot — every exit of k_dfs's fast tier and k_graph itself write it (round 3: the early
+    T_NEEDS_BIG exit wrote nothing).  Rows against the oracle, in a workspace an earlier batch has used."""
+    rng = np.random.default_rng(9090)
+
+    def rand_seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    long_t = rand_seq(2600)
+    dead = long_t[:900] + rand_seq(12)                           # a branch above the threshold that leads nowhere
+    bare = rand_seq(2600)                                        # same slot, an earlier batch: the bare reference
+    plain = rand_seq(300)
+    keys, counts = _db_from_reads([(long_t, 60), (dead, 30), (bare, 80), (plain, 50)], 31, None)
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": 31, "canonical": True, "keys": keys, "counts": counts})
+    finder = BatchFinder(jf)
+    first = finder.rows([("plain", plain), ("bare", bare)])       # leaves a reference maximum in slot 1
+    assert [len(r) for r in first] == [1, 1]
+    targets = [("plain", plain), ("long", long_t)]
+    rows = finder.rows(targets)                                   # the same workspace, lean delivery
+    want = [ko.target_rows(ko.analyse_target(s_, n_, cpu), "mem.jf") for n_, s_ in targets]
+    assert rows == want
+    raw = finder.run_raw([t[1] for t in targets])
+    assert int(raw["path_off"][2] - raw["path_off"][1]) == 1      # one path ...
+    assert int(raw["node_off"][2] - raw["node_off"][1]) == 2570   # ... and no walk node kept (the branch was a dead end)
+    b = finder._ensure(2, len(plain) + len(long_t))
+    b.set_targets([plain, long_t])
+    b.run(kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_DELIVER | kmlib.KM_DELIVER_LEAN | kmlib.KM_DELIVER_COUNT16)
+    b.wait_result()
+    v = b.result()
+    # a dead end registers no node: the graph is the bare chain after all, and what is delivered for it is ITS
+    # maximum (90 = both reads over the shared prefix), not the 80 the earlier batch left in the slot
+    want_max = int(np.max(ko.analyse_target(long_t, "long", cpu)["counts"]))
+    assert want_max == 90 and int(v["ref_max_cov"][1]) == want_max and int(v["ref_max_cov"][0]) == 50
+    db.close()
+
+
+def test_kmjf_broadcast_with_one_device_and_its_argument_errors():
+    """kmjf_broadcast (include/kmgpu.h): the single-process multi-GPU entry.  One device = a plain upload; no
+    device, a device named twice or a device that does not exist are refused before anything is allocated."""
+    case = synth.make_case(n_targets=20, length=200, n_keys=50_000, seed=5)
+    db = kmlib.Database.from_records(case["keys"], case["counts"], 31)
+    reps = db.broadcast([0])
+    assert len(reps) == 1 and reps[0] is db
+    assert (db.query(case["keys"][:5000]) == case["counts"][:5000]).all()
+    for bad in ([], [0, 0], [0, 99]):
+        db2 = kmlib.Database.from_records(case["keys"][:100], case["counts"][:100], 31)
+        with pytest.raises(kmlib.KmError) as e:
+            db2.broadcast(bad)
+        assert e.value.code == 4                                  # KM_E_ARG
+        db2.close()
+    db.close()
+
+
+def test_rccl_process_group_of_one_rank(tmp_path):
+    """The multi-process path (km_amd.dist: torch.distributed, backend nccl = RCCL) with a process group of ONE
+    rank on this box's GPU: the records are broadcast (to the rank itself), the table is built from the device
+    buffer, the catalog comes back as the golden TSV — so that the first execution of the nccl branch is not on
+    an 8-GPU node."""
+    import subprocess
+    import sys
+    child = r"""
+import json, os, socket, sys
+sys.path.insert(0, %(root)r)
+os.chdir(os.path.join(%(root)r, "tests"))
+import torch
+import torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+from km_amd import dist as kd
+from oracle import km_oracle as ko
+cat = sorted(os.listdir("./data/catalog/GRCh38"))
+targets = [(os.path.splitext(f)[0], ko.read_fasta_concat("./data/catalog/GRCh38/" + f)) for f in cat]
+blocks = kd.find_mutation_sharded(targets, "./data/jf/03H116_ITD.jf")
+lines = [r for blk in blocks for r in blk]
+json.dump({"lines": lines, "backend": dist.get_backend(), "world": dist.get_world_size()}, open(%(out)r, "w"))
+dist.destroy_process_group()
+"""
+    out = str(tmp_path / "nccl1.json")
+    subprocess.check_call([sys.executable, "-c", child % {"root": os.path.dirname(HERE), "out": out}],
+                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1"))
+    got = json.load(open(out))
+    assert got["backend"] == "nccl" and got["world"] == 1
+    gold = _load("fixtures_tsv.json")["cases"]
+    case = [c for c in gold if len(c["targets"]) == 9 and c["db"].endswith("03H116_ITD.jf")][0]
+    assert got["lines"] == case["lines"][11:]

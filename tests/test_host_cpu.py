@@ -100,6 +100,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.km_strerror(2).decode().startswith("not a Jellyfish")
 
 
+def test_kmjf_broadcast_refuses_bad_arguments_without_touching_a_gpu():
+    """The single-process multi-GPU entry of the C-ABI exists and fails cleanly: no device list (KM_E_ARG) before any
+    HIP call, and — on a box without a GPU, like the one the CPU suite runs on — one device gives an error code,
+    not a crash."""
+    import ctypes as C
+    lib = kmlib.load()
+    keys = np.arange(10, dtype=np.uint64)
+    db = kmlib.Database.from_records(keys, np.ones(10, np.uint32), 31)
+    out = (C.c_void_p * 1)()
+    assert lib.kmjf_broadcast(db._h, None, 0, out) == 4                       # KM_E_ARG
+    dev = (C.c_int * 2)(0, 0)
+    assert lib.kmjf_broadcast(db._h, dev, 2, (C.c_void_p * 2)()) == 4        # a device named twice
+    n = C.c_int(0)
+    if lib.km_device_count(C.byref(n)) != 0 or n.value == 0:
+        rc = lib.kmjf_broadcast(db._h, (C.c_int * 1)(0), 1, out)
+        assert rc != 0 and lib.km_last_error()
+    db.close()
+
+
 def test_native_reader_matches_oracle_reader(tmp_path):
     """Host-only ABI calls: kmjf_open / kmjf_info / kmjf_records need no GPU."""
     from oracle import jf_reader as jr
