@@ -351,6 +351,8 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   }
   hipLaunchKernelGGL(k_dir_capacity, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
                      (uint64_t)n_buckets, unit, tv.cshift);
+  // (KM_TABLE_LEAN_CROWDED=0: round 3's rule, a second doubling before a bucket becomes a two-choice table)
+  const int lean_crowded = getenv("KM_TABLE_LEAN_CROWDED") ? atoi(getenv("KM_TABLE_LEAN_CROWDED")) : 1;
   const int MAX_ROUNDS = 5;             // CAP_MAX_GEN dry rounds, up to two more doublings found by the real
                                         // insert, then one final round that places every key wherever it fits
   unsigned long long meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -397,7 +399,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
                 (unsigned long long)n_slots, meta[2]);
       if (meta[2]) {
         hipLaunchKernelGGL(k_dir_grow, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
-                           (uint64_t)n_buckets, tv.cshift);
+                           (uint64_t)n_buckets, tv.cshift, lean_crowded);
         continue;
       }
       dry_rounds = (int)CAP_MAX_GEN;               // nothing to grow: go straight to the insert
@@ -451,7 +453,7 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
     if (final_round) break;
     if (meta[2] == 0) break;
     hipLaunchKernelGGL(k_dir_grow, dim3(grid_for((uint64_t)n_buckets, 256)), dim3(256), 0, st, caps,
-                       (uint64_t)n_buckets, tv.cshift);
+                       (uint64_t)n_buckets, tv.cshift, lean_crowded);
   }
   if (getenv("KM_BUILD_VERBOSE"))
     fprintf(stderr, "libkmgpu: table built in %d round(s): %llu slots for %llu groups, max_probe %u\n",

@@ -106,7 +106,9 @@ __global__ void k_dir_capacity(uint32_t* caps, uint64_t n, uint32_t unit, uint32
 }
 
 // Double every flagged bucket that may still grow (and clear the flags).
-__global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift) {
+// lean_crowded: a class-mode bucket that would double a second time is turned into a plain two-choice table at
+// the size it has (load 1/4) instead of at twice that (load 1/8): half the slots for k_dfs to hold in its lanes
+__global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift, int lean_crowded) {
   const uint64_t NC = 1ull << cshift;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
@@ -115,7 +117,9 @@ __global__ void k_dir_grow(uint32_t* caps, uint64_t n, uint32_t cshift) {
     const uint32_t gen = cap_gen(c);
     // doubling; the extra step of a bucket in which a key fitted neither of its two pairs
     // (a few hundred buckets in 10^8) quadruples it, so that the rebuild settles it for good
-    uint64_t slots = shape_capacity((gen >= CAP_MAX_GEN ? 8ull : 4ull) * (c & CAP_SIZE), NC);
+    uint64_t mult = gen >= CAP_MAX_GEN ? 8ull : 4ull;
+    if (lean_crowded && gen + 1 == CAP_MAX_GEN && 2ull * (c & CAP_SIZE) >= 2 * NC) mult = 2ull;
+    uint64_t slots = shape_capacity(mult * (c & CAP_SIZE), NC);
     // the last doubling of a class-mode bucket turns it into a plain hash table over all its
     // pairs (an odd multiple of NC, see home_slot): its classes are too unevenly filled
     if (gen + 1 >= CAP_MAX_GEN && slots >= 2 * NC) slots += NC;
