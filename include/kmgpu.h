@@ -236,6 +236,9 @@ int km_batch_set_targets_dev(km_batch_t* b, const uint8_t* d_bases, const uint64
 #define KM_RUN_COUNT_FETCHES 256
 /* Record the HIP events km_batch_timings reads (seven event records per run; off by default). */
 #define KM_RUN_TIMED 32
+/* With KM_RUN_TIMED: record the STAGE boundaries only (walk start / end, graph end, delivery) — the walk stage as it
+ * runs in production, without the two event records between its three kernels; km_batch_timings [3], [4], [5] are 0. */
+#define KM_RUN_TIMED_STAGES 512
 /* Kept for callers of round 2: a batch's kernels now ALWAYS run in `stream`, in order (the pass over the
  * unflagged targets, k_graph_pure, used to run beside k_dfs on a side stream unless this flag was given;
  * it follows k_dfs, inside the graph stage of km_batch_timings).  The flag changes nothing. */

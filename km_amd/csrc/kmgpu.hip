@@ -299,7 +299,9 @@ extern "C" int kmjf_upload_from_device(kmjf_t* h, int device, const uint64_t* d_
   // KM_DIR_LOG2: log2 of the bucket count (default: about one bucket per 2 entries; a
   // super-k-mer brings ~w entries of its own, so most buckets of real data are empty)
   uint32_t n_buckets = 1024;
-  while ((uint64_t)n_buckets * 2 < max_entries && n_buckets < (1u << 30)) n_buckets <<= 1;
+  // (at most 1.5 entries per bucket: with 1.9 — a 500 M-k-mer sample under the old rule of 2 — half as many more buckets
+  // double and the table takes 144 B per k-mer instead of ~105)
+  while ((uint64_t)n_buckets * 3 < max_entries * 2 && n_buckets < (1u << 30)) n_buckets <<= 1;
   if (const char* dl = getenv("KM_DIR_LOG2")) { int v = atoi(dl); if (v >= 4 && v <= 30) n_buckets = 1u << v; }
   const uint32_t n_chunks = (uint32_t)(((uint64_t)n_buckets + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK);
   const uint64_t dir_words = (uint64_t)n_chunks * SCAN_CHUNK;
@@ -933,6 +935,7 @@ struct km_batch {
   DevBuf<uint32_t> d_n_nodes, d_n_ref, d_status, d_gstatus, d_npaths, d_pathbase, d_need_full, d_t_nruns, d_t_refmax;
   uint32_t pure_lds = 0;
   bool timed = false;                  // the last run recorded its timing events
+  bool timed_fine = false;             // ... those between the kernels of the walk stage as well
   hipGraph_t graph = nullptr;          // captured step (KM_RUN_HIPGRAPH)
   hipGraphExec_t gexec = nullptr;
   int graph_stages = 0;
@@ -1581,6 +1584,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   const bool want_c16 = (stages & KM_DELIVER_COUNT16) != 0;
   if (stages & KM_STAGE_WALK) b->count_fetches = (stages & KM_RUN_COUNT_FETCHES) != 0;
   const bool want_timed = (stages & KM_RUN_TIMED) != 0;
+  const bool timed_fine = want_timed && !(stages & KM_RUN_TIMED_STAGES);
   const bool serial = (stages & KM_RUN_SERIAL) != 0;
   stages &= (KM_STAGE_WALK | KM_STAGE_GRAPH);
   b->deliver_pending = b->result_ready = false;
@@ -1628,6 +1632,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   bool graph_launched = false;
   // a captured step has no host round trips inside
   b->timed = want_timed;
+  b->timed_fine = timed_fine;
   const bool capturing = want_graph && st != nullptr && (stages & KM_STAGE_WALK);   // the NULL stream cannot be captured
   if (capturing) {
     b->timed = false;
@@ -1641,10 +1646,10 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     ht[3] = host_trace ? host_now_us() : 0;
     if (b->timed) HIPCHK(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(k_pack, dim3((b->n_targets + PACK_WAVES - 1) / PACK_WAVES), dim3(64 * PACK_WAVES), 0, st, wa);
-    if (b->timed) HIPCHK(hipEventRecord(b->ev[3], st));
+    if (b->timed && timed_fine) HIPCHK(hipEventRecord(b->ev[3], st));
     if (b->n_items)
       launch_seed(b->n_items, st, wa, b->count_fetches);
-    if (b->timed) HIPCHK(hipEventRecord(b->ev[4], st));
+    if (b->timed && timed_fine) HIPCHK(hipEventRecord(b->ev[4], st));
     // a batch's kernels run in ONE stream, in order (k_graph_pure after k_dfs): batches overlap with each
     // other, every launch stream on a hardware queue of its own (see "streams" above).  (Round 2 ran
     // k_graph_pure beside k_dfs on a side stream per batch; KM_RUN_SERIAL selected today's order.)
@@ -1927,9 +1932,11 @@ static void read_timings(km_batch* b) {
   (void)hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]);
   (void)hipEventElapsedTime(&b->ms[2], b->ev[0], b->ev[2]);
-  (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
-  (void)hipEventElapsedTime(&b->ms[4], b->ev[0], b->ev[3]);
-  (void)hipEventElapsedTime(&b->ms[5], b->ev[4], b->ev[1]);
+  if (b->timed_fine) {
+    (void)hipEventElapsedTime(&b->ms[3], b->ev[3], b->ev[4]);
+    (void)hipEventElapsedTime(&b->ms[4], b->ev[0], b->ev[3]);
+    (void)hipEventElapsedTime(&b->ms[5], b->ev[4], b->ev[1]);
+  }
   if (b->timed_deliver) {
     (void)hipEventElapsedTime(&b->ms[6], b->ev[2], b->ev[5]);
     (void)hipEventElapsedTime(&b->ms[7], b->ev[5], b->ev[6]);

@@ -22,6 +22,7 @@ KM_STAGE_WALK, KM_STAGE_GRAPH, KM_RUN_HIPGRAPH, KM_RUN_DELIVER, KM_DELIVER_LEAN,
 KM_DELIVER_COUNT16 = 128        # node counts cross PCIe as 16-bit values + the list of the exact counts >= 65535
 KM_RUN_COUNT_FETCHES = 256      # count the table slots read (sizes.table_fetches; a diagnostic, 2 % of a step)
 KM_RUN_SERIAL = 64
+KM_RUN_TIMED_STAGES = 512       # with KM_RUN_TIMED: stage boundaries only (no event records between the walk stage's kernels)
 T_OK, T_NODE_LIMIT, T_REPEAT_KMER, T_EMPTY, T_BAD_BASE, T_INTERNAL = range(6)
 
 # every symbol include/kmgpu.h declares (tests check the library exports them all)

@@ -171,6 +171,26 @@ def make_case(n_targets=100, length=500, k=31, n_keys=200_000, seed=HEADLINE_SEE
             "key_target": tids}
 
 
+def fast_canonical_keys(n, seed=0, k=31):
+    """`n` DISTINCT canonical k-mers without a sort (real-size samples: example/run_leucegene.sh:24 counts with
+    -s 799063683): the numbers seed_offset .. seed_offset + n - 1 pushed through a bijection of the 2k - 4 middle
+    bits, between a first base A and a last base in {A, C, G} — the reverse complement of such a k-mer starts with
+    T, G or C, so the k-mer itself is the canonical one.  Unsorted."""
+    bits = 2 * k - 4
+    assert 8 <= bits <= 58 and 0 < n < (1 << bits) - (1 << 20)
+    M = np.uint64((1 << bits) - 1)
+    idx = np.arange(n, dtype=np.uint64)
+    x = (idx + np.uint64((int(seed) * 0x9E3779B1) % (1 << 20))) & M
+    for mul, sh in ((0xFF51AFD7ED558CCD, 29), (0xC4CEB9FE1A85EC53, 31), (0x9E3779B97F4A7C15, 27)):
+        x ^= x >> np.uint64(sh)                       # (each step is a bijection on `bits` bits)
+        x *= np.uint64(mul)
+        x &= M
+    x ^= x >> np.uint64(bits // 2)
+    x <<= np.uint64(2)
+    x |= idx % np.uint64(3)
+    return x
+
+
 def make_sample(target_seqs, seed, k=31, n_keys=2_000_000, cov=(50, 2000), variant_frac=0.5,
                 vaf=(0.1, 0.6), kinds=("snv", "ins", "del", "dup")):
     """One synthetic SAMPLE for BASELINE config 5: a k-mer count table for a GIVEN
@@ -204,6 +224,16 @@ def make_sample(target_seqs, seed, k=31, n_keys=2_000_000, cov=(50, 2000), varia
     keys = km.canonical(np.concatenate(all_k), k) if all_k else np.zeros(0, np.uint64)
     cnts = np.concatenate(all_c) if all_c else np.zeros(0, np.int64)
     n_pad = max(0, n_keys - keys.size)
+    if n_pad > 20_000_000 and 12 <= k <= 31:
+        # a real-size sample: distinct pads by construction (no sort of 10^8 keys), minus the few that are a real key
+        uk, first = np.unique(keys, return_index=True)
+        uc = np.minimum(cnts[first], 0xFFFFFFFF).astype(np.uint32)
+        pads = fast_canonical_keys(n_pad, seed, k)
+        at = np.searchsorted(uk, pads)
+        at[at >= uk.size] = max(0, uk.size - 1)
+        pads = pads[uk[at] != pads] if uk.size else pads
+        pc = (np.arange(pads.size, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(16)) % np.uint32(49) + np.uint32(2)
+        return np.concatenate([uk.astype(np.uint64), pads]), np.concatenate([uc, pc.astype(np.uint32)])
     if n_pad:
         hi = (1 << (2 * k)) if 2 * k < 64 else int(np.iinfo(np.uint64).max)
         keys = np.concatenate([keys, km.canonical(rng.integers(0, hi, size=n_pad, dtype=np.uint64), k)])

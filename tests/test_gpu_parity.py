@@ -1576,3 +1576,65 @@ dist.destroy_process_group()
     gold = _load("fixtures_tsv.json")["cases"]
     case = [c for c in gold if len(c["targets"]) == 9 and c["db"].endswith("03H116_ITD.jf")][0]
     assert got["lines"] == case["lines"][11:]
+
+
+def test_real_size_sample_500M_kmers():
+    """A sample of real size (example/run_leucegene.sh:24 counts with -s 799063683; the largest table of earlier
+    rounds held 330 M k-mers): 500 M distinct canonical 31-mers — 10^9 table entries, 2^29 minimizer buckets, ~50 GB
+    of HBM — built on the device, every bound of the 100 M-key table kept (probe length, bytes per k-mer); lookups of
+    stored and absent keys and the walk + path search of 400 targets whose k-mers lie among them, against the plain-C
+    oracle holding every key."""
+    from oracle import c_oracle
+    case = synth.make_case(n_targets=400, length=500, k=31, n_keys=1, seed=4242, variant_frac=0.5,
+                           variants_per_target=(1, 2), exact_pad=False)
+    real_k, real_c = case["keys"][:case["n_real"]], case["counts"][:case["n_real"]]
+    order = np.argsort(real_k)
+    real_k, real_c = real_k[order], real_c[order]
+    n_pad = 500_000_000
+    pads = synth.fast_canonical_keys(n_pad, 17, 31)
+    at = np.searchsorted(real_k, pads)
+    at[at >= real_k.size] = real_k.size - 1
+    keep = real_k[at] != pads
+    del at
+    pads = pads[keep]
+    del keep
+    keys = np.concatenate([real_k, pads])
+    counts = np.concatenate([real_c, ((np.arange(pads.size, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(20)) % np.uint32(60) + np.uint32(1)])
+    del pads
+    assert keys.size >= 500_000_000
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    info = db.info
+    assert info.n_records == keys.size and info.n_groups <= 2 * info.n_records
+    assert 2 <= info.max_probe <= 8, info.max_probe
+    # (the bucket count is a power of two: 1.9 entries per bucket here against 1.5 in the 100 M-key table, so more
+    # buckets double — 144 B per k-mer against 103)
+    assert info.table_bytes < 160 * keys.size
+    co = c_oracle.COracle(keys, counts, 31)
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, keys.size, size=2_000_000)
+    assert (db.query(keys[pick]) == counts[pick]).all()
+    assert (db.query(jr.revcomp_np(keys[pick[:200_000]], 31)) == counts[pick[:200_000]]).all()
+    absent = rng.integers(0, 1 << 62, size=20_000, dtype=np.uint64)
+    want = np.array([co.lib.ko_query(co.h, int(x)) for x in absent], dtype=np.uint32)
+    assert (db.query(absent) == want).all()
+    T = 400
+    b = kmlib.Batch(db, max_targets=T, max_total_bases=T * 500)
+    blob = np.frombuffer(b"ACGT", dtype=np.uint8)[case["targets"]].reshape(-1)
+    b.set_targets_packed(blob, np.arange(T + 1, dtype=np.uint64) * np.uint64(500))
+    b.run(kmlib.KM_STAGE_WALK | kmlib.KM_STAGE_GRAPH | kmlib.KM_RUN_DELIVER)
+    r = b.fetch()
+    assert (r["status"] == 0).all()
+    noff, poff = r["node_off"].astype(np.int64), r["path_off"].astype(np.int64)
+    n_multi = 0
+    for t in range(T):
+        w = co.analyse(case["targets"][t])
+        assert w["status"] == 0
+        assert (r["node_kmer"][noff[t]:noff[t + 1]] == w["kmers"]).all(), t
+        assert (r["node_count"][noff[t]:noff[t + 1]] == w["counts"]).all(), t
+        assert int(r["probes"][t]) == w["probes"], t
+        got = [kmlib.expand_path(r, p).tolist() for p in range(poff[t], poff[t + 1])]
+        assert got == w["paths"] and r["path_min_cov"][poff[t]:poff[t + 1]].tolist() == w["min_cov"], t
+        n_multi += len(got) > 1
+    assert n_multi > 100
+    b.close()
+    db.close()
