@@ -1356,8 +1356,8 @@ static uint32_t words_cap_for(uint32_t len) { return round_up((len + 31) / 32 + 
 // their slot of the position table (a fifth of them with the table at load 1/2): room for a quarter of the target's
 // k-mers + every allowed extra node + 64 frames, at load <= 3/4 (what does not fit goes to the large tier)
 static uint32_t walk_hs_cap(uint32_t nref) { return round_up((uint32_t)(((uint64_t)(nref / 4 + FAST_EXTRA + 64) * 4 + 2) / 3), 64); }
-// slots of its position table: the power of two >= twice the target's k-mers
-static uint32_t walk_pcap(uint32_t nref) { uint32_t p = 64; while (p < 2 * nref) p <<= 1; return p; }
+// slots of its position table: the power of two >= four times the target's k-mers (load <= 1/4: a tenth of the k-mers lose their slot)
+static uint32_t walk_pcap(uint32_t nref) { uint32_t p = 64; while (p < 4 * nref) p <<= 1; return p; }
 
 static bool fast_fits(const km_batch* b, uint32_t nref, uint32_t bcap) {
   const uint32_t len = nref + (uint32_t)b->db->k - 1;
