@@ -513,9 +513,9 @@ struct ChildRule {       // what get_child needs beside the counts (wave-uniform
   uint32_t thr_T;
 };
 // One slot evaluated by its lane.  `hintf(k-mer)`: is it probably a node of the walk (the hint only).
-template <class HintF>
-__device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
-                                      HintF& hintf, uint32_t* info);
+// (returns the single kept child, 0 if there is none: the hint is worked out by the caller, for all sets of a bucket
+// together — its LDS reads are then in flight side by side instead of set after set)
+__device__ inline uint64_t slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw, uint32_t* info);
 // lo / hi: the bucket's directory words (wave-uniform)
 template <class HintF>
 __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, uint32_t bucket, uint32_t lo, uint32_t hi,
@@ -537,12 +537,20 @@ __device__ inline void bucket_load_wave(const TableView& t, const ChildRule& r, 
         }
       }
     }
+    uint64_t child[BUCKET_LANES_SETS];
 #pragma unroll
     for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) {
+      child[i] = 0;
       if (64u * i < S) {                             // wave-uniform
-        if (b->tag[i] != EMPTY) slot_successor(t, r, b->tag[i], zw[i], hintf, &b->info[i]);
+        if (b->tag[i] != EMPTY) child[i] = slot_successor(t, r, b->tag[i], zw[i], &b->info[i]);
       }
     }
+    // the hints of every set, branch-free (the reads of one set do not wait for those of the set before it)
+    bool hint[BUCKET_LANES_SETS];
+#pragma unroll
+    for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) hint[i] = (64u * i < S) ? hintf(child[i]) : false;
+#pragma unroll
+    for (uint32_t i = 0; i < BUCKET_LANES_SETS; ++i) if ((b->info[i] & SLOT_SINGLE) && hint[i]) b->info[i] |= SLOT_HINT;
     *fetches += S;
   }
 }
@@ -646,9 +654,7 @@ __device__ inline uint32_t child_mask(uint4 c, double ratio, double nc) {
 __device__ inline uint32_t child_mask(uint4 c, double ratio, int64_t n_cutoff) { return child_mask(c, ratio, (double)n_cutoff); }
 // device_common.h: BucketLanes.  What Jellyfish.get_child (km/utils/Jellyfish.py:55-72) makes of one
 // slot, for the k-mers x whose suffix x[1:] is the slot's (k-1)-mer in the orientation its side bit names.
-template <class HintF>
-__device__ inline void slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw,
-                                      HintF& hintf, uint32_t* info) {
+__device__ inline uint64_t slot_successor(const TableView& t, const ChildRule& r, uint64_t tag, uint64_t zw, uint32_t* info) {
   const uint32_t z = (uint32_t)zw, w = (uint32_t)(zw >> 32);
   const uint32_t s0 = z & 0xFFFFu, s1 = z >> 16, s2 = w & 0xFFFFu, s3 = w >> 16;   // slot order
   const bool esc = s0 == COUNT_ESCAPE || s1 == COUNT_ESCAPE || s2 == COUNT_ESCAPE || s3 == COUNT_ESCAPE;
@@ -660,7 +666,7 @@ __device__ inline void slot_successor(const TableView& t, const ChildRule& r, ui
   if (none) m4 = 0;
   const bool single = !esc && m4 != 0 && (m4 & (m4 - 1)) == 0;
   *info = 0;
-  if (!single) return;
+  if (!single) return 0;
   const uint32_t si = (uint32_t)__ffs((int)m4) - 1;
   const uint32_t side = t.canonical ? (uint32_t)(tag & 1) : 0u;
   const uint32_t c = side ? 3u - si : si;                        // child base
@@ -669,8 +675,8 @@ __device__ inline void slot_successor(const TableView& t, const ChildRule& r, ui
   // P: the (k-1)-mer as the walk reads it (x[1:])
   const uint64_t P = (t.canonical && side) ? revcomp(G, t.k - 1) : G;
   const uint64_t child = (P << 2) | c;                           // x[1:] + c, 2k bits
-  const bool hint = hintf(child);
-  *info = c | SLOT_SINGLE | (hint ? SLOT_HINT : 0u) | (cnt << 16);
+  *info = c | SLOT_SINGLE | (cnt << 16);
+  return child;
 }
 
 // Sums below *below* all have the threshold T = ceil(n_cutoff) (sum * ratio <= n_cutoff: the float64

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -827,6 +829,68 @@ void text_free(char* text) {
   free(p);
 }
 
+// ---- the team of worker threads, kept between calls.  A consumer reports batch after batch (tools/kmclient.cpp: one
+// call per 10 000 targets every 2 ms): starting sixteen threads and faulting in sixteen fresh megabyte buffers per call
+// was a fifth of a call.  One team per process, taken by one call at a time (a second concurrent call starts
+// threads of its own, as every call used to); the workers' row buffers keep their capacity.
+struct Team {
+  std::mutex in_use;                         // held by the call that runs on the team
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> threads;          // workers 1 .. (the caller is worker 0)
+  std::vector<std::string> buf;              // per worker, reused
+  std::function<void(unsigned)> job;
+  unsigned n_active = 0, pending = 0;
+  unsigned long long generation = 0;
+  bool quit = false;
+  void loop(unsigned me) {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::function<void(unsigned)> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return quit || (generation != seen && me < n_active); });
+        if (quit) return;
+        seen = generation;
+        f = job;
+      }
+      f(me);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // run job(0 .. n - 1), job(0) on the calling thread
+  void run(unsigned n, const std::function<void(unsigned)>& f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while (threads.size() + 1 < n) { const unsigned me = (unsigned)threads.size() + 1; threads.emplace_back([this, me] { loop(me); }); }
+      job = f;
+      n_active = n;
+      pending = n - 1;
+      ++generation;
+    }
+    cv_go.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+    n_active = 0;
+  }
+  ~Team() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv_go.notify_all();
+    for (std::thread& th : threads) th.join();
+  }
+};
+Team& team() {
+  static Team* t = new Team;                 // (never destroyed: its threads must not outlive a static's destructor at exit)
+  return *t;
+}
+
 }  // namespace
 
 extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_t** row_off_out,
@@ -882,7 +946,13 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
     unsigned n_thr = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     if (const char* e = getenv("KM_REPORT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (unsigned)v; }
     n_thr = std::min<unsigned>(n_thr, std::max<uint32_t>(1, n / 64));     // small batches: no threads
-    std::vector<std::string> wbuf(n_thr);
+    // the team's buffers when this call gets the team, buffers of its own otherwise
+    std::unique_lock<std::mutex> team_lock(team().in_use, std::try_to_lock);
+    const bool on_team = team_lock.owns_lock() && n_thr > 1;
+    std::vector<std::string> own_buf;
+    if (on_team) { if (team().buf.size() < n_thr) team().buf.resize(n_thr); }
+    else own_buf.resize(n_thr);
+    std::vector<std::string>& wbuf = on_team ? team().buf : own_buf;
     std::atomic<uint32_t> next(0), next_copy(0), arrived(0);
     std::atomic<bool> failed(false);
     std::atomic<int> phase(0);            // 1: offsets and the text buffer are ready, -1: allocation failed
@@ -894,6 +964,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
       try {
         Scratch w;
         std::string& out = wbuf[me];
+        out.clear();
         out.reserve((size_t)n * 1600 / n_thr + 65536);
         for (uint32_t c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) {
           chunk[c] = ChunkRec{me, out.size()};
@@ -1016,6 +1087,8 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
     };
     if (n_thr <= 1) {
       work(0);
+    } else if (on_team) {
+      team().run(n_thr, work);
     } else {
       std::vector<std::thread> pool;
       for (unsigned q = 1; q < n_thr; ++q) pool.emplace_back(work, q);

@@ -599,6 +599,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
 #endif
 #ifdef KM_DFS_COUNTERS
   uint32_t dc_nonres = 0, dt_nonres = 0, dc_bigS = 0;
+  uint32_t dt_post = 0, dt_pre = 0, dt_chain = 0, dt_tail = 0, dt_pop = 0, dt_seed0 = 0;
   uint32_t dc_slow = 0, dc_spec = 0, dc_rec = 0, dc_bload = 0, dc_gen = 0, dc_runs = 0, dc_full = 0, dc_v0 = 0, dc_steps = 0, dc_noalign = 0;
   uint32_t dt_spec = 0, dt_book = 0, dt_gen = 0, dt_bload = 0, dt_rejoin = 0, dt_unwind = 0, dt_align = 0, dt_t0 = 0;   // 10 ns units
 #define KM_DC(x) (++(x))
@@ -749,10 +750,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
     return (uint32_t)(kmer_at(i) >> 2);
   };
   // the index of the target k-mer y, if y is one that owns its slot of the position table (the others are in the node set)
+  // (branch-free: an empty slot compares against the target's first k-mer and is discarded — callers that look several
+  // k-mers up side by side get their LDS reads in flight together)
   auto ref_index = [&](uint64_t y) -> uint32_t {
     const uint32_t p_ = (uint32_t)pos[pos_home((uint32_t)(y >> 2))];
-    if (p_ == POS_NONE) return NO_NODE;
-    return kmer_at(p_) == y ? p_ : NO_NODE;
+    const bool some = p_ != POS_NONE;
+    return (kmer_at(some ? p_ : 0u) == y && some) ? p_ : NO_NODE;
   };
   // y is probably a node (a target k-mer, or a k-mer sitting in its home slot of the node set): a hint
   auto node_hint = [&](uint64_t y) -> bool { return ref_index(y) != NO_NODE || keys[set_home(y >> 2, cap)] == y; };
@@ -891,6 +894,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
         const uint32_t b = (uint32_t)__ffs((int)bits) - 1;
         bits &= bits - 1;
         const uint32_t i = w * 32 + b;
+        KM_DT0();
         uint64_t cur = kmer_at(i);
         // (the seed is a node for good: its frame's set slot is never looked at)
         if (lane == 0) { fk[0] = cur; fc[0] = 0; fs[0] = 0u; }
@@ -898,6 +902,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
         uint4 c4 = make_uint4(0, 0, 0, 0);
         bool need_expand = true;
         step_sync();
+        KM_DT(dt_seed0);
         while (true) {
           if (++steps > DFS_STEP_LIMIT) { st = T_INTERNAL; break; }
           KM_DFS_STAMP(0);                                 // loop control + whatever was not stamped
@@ -933,6 +938,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
               dfs_prev = (uint32_t)pend.t_key;
 #endif
             }
+            KM_DT(dt_post);
             KM_DFS_STAMP(3);                               // directory word, home pair, request                               // thresholds + key and request of the next lookup
 #ifdef KM_DFS_STAMPS
             ++dfs_steps;
@@ -948,6 +954,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
           // child to the general step below, which treats it exactly as before.  What was
           // looked up past it is dropped: lookups have no side effects.
           if (mask != 0 && (mask & (mask - 1)) == 0 && n_nodes <= a.max_node) {
+            KM_DT0();
             int64_t room64 = 64;
             room64 = min(room64, (int64_t)a.max_stack - (int64_t)depth);
             room64 = min(room64, (int64_t)a.fcap - (int64_t)depth);
@@ -979,6 +986,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             uint64_t T;
             bool hint;
             slow_state(child, &T, &hint);
+            KM_DT(dt_pre);
             // the rest of a step — the tag is not among the lanes, or its slot does not name a single
             // child — kept out of the loop's hot path; true: the run goes on, false: (c4, mask) hold the
             // expansion of x and the run ends
@@ -1151,6 +1159,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                 // themselves are not kept in the lanes
                 c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
               }
+              KM_DT0();
               const uint32_t xm = child_mask(c4, a.ratio, a.nc);
               KM_DFS_STAMP(13);                            // chain: full expansion
               if (xm != 0 && (xm & (xm - 1)) == 0) {
@@ -1158,6 +1167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                 cnt = pick4(c4, c);
                 child = ((x << 2) | c) & tab.kmask;
                 slow_state(child, &T, &hint);
+                KM_DT(dt_tail);
                 return true;
               }
               mask = xm;
@@ -1170,6 +1180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             // bucket change or other slow step.
             for (;;) {
               bool was_hit = false, stop = false;
+              KM_DT0();
               for (;;) {
                 if (n >= room || hint) { stop = true; break; }
                 if (lane == n) { rkey = child; rcnt = cnt; }
@@ -1191,6 +1202,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                 child = ((x << 2) | c) & tab.kmask;
                 T = tag_of_suffix(child);
               }
+              KM_DT(dt_chain);
               if (stop) break;
               if (!step_slow(was_hit)) break;
             }
@@ -1384,12 +1396,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
           // else: the child's __extend returns at once (len(stack) > max_stack)
         }
         if (st != T_OK) break;
+        KM_DT0();
         mem_sync();
         for (uint32_t j = 1 + lane; j < depth; j += 64) {
           const uint32_t s = fs[j];
           if (meta_state(state[s]) == ST_ONSTACK) state[s] = slot_meta(ST_POPPED, 0);
         }
         step_sync();
+        KM_DT(dt_pop);
         // the next seed's __extend call (there is one unless this was the last
         // target k-mer) checks the node limit first
         if (n_nodes > a.max_node && i + 1 < n_ref) st = T_NODE_LIMIT;
@@ -1708,6 +1722,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
 #ifdef KM_DFS_COUNTERS
     o[19] = dt_spec; o[20] = dt_book; o[21] = dt_gen; o[22] = dt_bload; o[23] = dt_rejoin; o[24] = dt_unwind; o[25] = dt_align;
     o[26] = dc_nonres; o[27] = dt_nonres; o[28] = dc_bigS;
+    o[29] = ((unsigned long long)dt_post << 32) | dt_pre; o[30] = ((unsigned long long)dt_chain << 32) | dt_tail;
+    o[6] = ((unsigned long long)dt_pop << 32) | dt_seed0;
     o[9] = dc_slow; o[10] = dc_spec; o[11] = dc_rec; o[12] = dc_bload; o[13] = dc_gen; o[14] = dc_runs; o[15] = dc_full; o[16] = dc_v0; o[17] = dc_steps; o[18] = dc_noalign;
 #endif
     o[31] = 0x6c6966655f646673ull;

@@ -79,7 +79,15 @@ if COUNTERS:
     print("time per wave in (us, mean / p50 / max):")
     for j, nm in enumerate(tn):
         print("  %-36s %6.2f %6.2f %6.2f" % (nm, tt[:, j].mean(), np.median(tt[:, j]), tt[:, j].max()))
-    print("  accounted for: %.1f of a mean walk of %.1f us" % (tt.sum(axis=1).mean(), walk.mean()))
+    more = {"after an expansion (thresholds, prefetch)": rec[:, 29] >> 32, "run preamble": rec[:, 29] & 0xFFFFFFFF,
+            "chain steps in the lanes": rec[:, 30] >> 32, "tail of a slow step": rec[:, 30] & 0xFFFFFFFF,
+            "pops at the end of a seed": rec[:, 6] >> 32, "seed start": rec[:, 6] & 0xFFFFFFFF}
+    extra = 0.0
+    for nm, v in more.items():
+        v = v.astype(np.float64) / 100.0
+        extra += v.mean()
+        print("  %-36s %6.2f %6.2f %6.2f" % (nm, v.mean(), np.median(v), v.max()))
+    print("  accounted for: %.1f of a mean walk of %.1f us" % (tt.sum(axis=1).mean() + extra, walk.mean()))
     print("  non-resident lookups per wave: mean %.2f max %d, %.2f us each; largest bucket met by one: %d slots" %
           (rec[:, 26].mean(), rec[:, 26].max(), rec[:, 27].sum() / 100.0 / max(1, rec[:, 26].sum()), rec[:, 28].max()))
     for i in order[:6]:
