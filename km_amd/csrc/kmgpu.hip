@@ -978,6 +978,11 @@ struct km_batch {
   uint32_t big_entry = 0;              // nodes per slot of the region (0: tier off)
   uint64_t big_region = 0;             // its first node (the region sits in front of the fast-tier layout)
   uint32_t n_big_dev = 0;              // targets it took in the last synchronised run
+  // Its two launches cost a step ~9 us when every kernel runs alone, needed or not.  They are launched once a
+  // delivery of this batch has reported a target for the large tier (the first such target of a workspace's life
+  // takes the host's path, as every one used to; KM_BIG_DEVICE=1 arms the tier from the first run)
+  bool bigdev_armed = false;
+  bool bigdev_ran = false;             // the last run launched it
   // host mirrors after sync
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
   unsigned long long h_overflow = 0;
@@ -1068,6 +1073,7 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
     // the device's large tier: BIG_DEV_SLOTS slots of the reference's own bound on a walk (MutationFinder.py:140-156)
     const uint64_t entry = (uint64_t)params->max_node + params->max_stack + 1;
     if (!getenv("KM_BIG_DEVICE_OFF") && entry < 0x7FFFFFFFull && entry * BIG_DEV_SLOTS * 12 <= BIG_DEV_MAX_BYTES) b->big_entry = (uint32_t)entry;
+    if (const char* e = getenv("KM_BIG_DEVICE")) b->bigdev_armed = atoi(e) != 0;
   }
   const uint64_t pool = max_total_bases + (uint64_t)max_targets * FAST_EXTRA + (uint64_t)b->big_entry * BIG_DEV_SLOTS;
   A(b->d_node_base0.alloc(max_targets));
@@ -1604,6 +1610,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
   ht[1] = host_trace ? host_now_us() : 0;
   if (want_graph && !serial && b->gexec && b->graph_stages == stages && b->graph_stream == st) {
     HIPCHK(hipGraphLaunch(b->gexec, st));
+    b->bigdev_ran = b->big_entry && b->bigdev_armed;      // (a flip of that state drops the captured step)
     b->ran_walk = true;
     b->ran_graph = true;
     b->synced = false;
@@ -1675,6 +1682,7 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     HIPCHK(hipGetLastError());
     if (b->timed) HIPCHK(hipEventRecord(b->ev[1], st));
     {
+      b->bigdev_ran = b->big_entry && b->bigdev_armed;
       int rc = launch_big_walk_dev(b, st);
       if (rc != KM_OK) return rc;
     }
@@ -1758,7 +1766,7 @@ static int big_walk_geometry(km_batch* b, WalkArgs& a) {
 // Workspaces of the device's own large tier (allocated before a step is launched or captured; they grow with the
 // longest target of the batch)
 static int ensure_bigdev_ws(km_batch* b) {
-  if (!b->big_entry) return KM_OK;
+  if (!b->big_entry || !b->bigdev_armed) return KM_OK;
   WalkArgs a;
   memset(&a, 0, sizeof a);
   int rc = big_walk_geometry(b, a);
@@ -1772,7 +1780,7 @@ static int ensure_bigdev_ws(km_batch* b) {
 // The device's own large tier, walk: one more launch behind the fast k_dfs, in its stream — BIG_DEV_SLOTS single-wave
 // blocks that leave at once unless the fast kernel appended targets to the list (WalkArgs::big_ctl).
 static int launch_big_walk_dev(km_batch* b, hipStream_t st) {
-  if (!b->big_entry) return KM_OK;
+  if (!b->big_entry || !b->bigdev_armed) return KM_OK;
   WalkArgs a;
   fill_walk_args(b, a);
   int rc = big_walk_geometry(b, a);
@@ -1789,7 +1797,7 @@ static int launch_big_walk_dev(km_batch* b, hipStream_t st) {
 }
 // ... and graph: behind the fast k_graph, over what it (or the large-tier walk's results) could not hold
 static int launch_big_graph_dev(km_batch* b, hipStream_t st) {
-  if (!b->big_entry) return KM_OK;
+  if (!b->big_entry || !b->bigdev_armed) return KM_OK;
   GraphArgs g;
   fill_graph_args(b, g);
   g.ncap = b->big_entry + 2;
@@ -1962,6 +1970,7 @@ extern "C" int km_batch_sync(km_batch_t* b) {
   std::vector<uint32_t> big;
   for (uint32_t t = 0; t < n; ++t) if (b->h_status[t] == T_NEEDS_BIG) big.push_back(t);
   b->n_big = (uint32_t)big.size();
+  if (b->big_entry && !big.empty() && !b->bigdev_armed) { b->bigdev_armed = true; drop_graph(b); }
   std::vector<char> force_big(n, 0);
   bool changed = false;
   if (!big.empty()) {
@@ -2047,6 +2056,10 @@ static int finish_result(km_batch* b, bool need_full) {
     }
     if (T[OT_SERIAL] != b->serial) return fail(KM_E_HIP, "delivery buffer out of step");
     const unsigned long long nh = T[OT_NEEDS_HOST];
+    if (b->big_entry && !b->bigdev_armed && ((nh & 1ull) || T[OT_N_BIG_DEV])) {
+      b->bigdev_armed = true;              // from the next run on, the device's own large tier is launched
+      drop_graph(b);                       // (a captured step does not contain its launches)
+    }
     if (!nh && b->count16 && T[OT_N_ESC] > OUT_ESC_CAP) {
       // more counts >= 65535 than the escape list holds: this batch is delivered with 32-bit counts
       if (attempt >= 4) return fail(KM_E_NOMEM, "result delivery keeps failing");
@@ -2133,7 +2146,7 @@ static void sizes_of_result(const km_batch* b, km_batch_sizes_t* s) {
   s->n_extra = T[OT_N_EXTRA];
   s->logical_probes = T[OT_PROBES];
   s->table_fetches = T[OT_FETCHES];
-  s->n_big_tier = b->n_big + (uint32_t)T[OT_N_BIG_DEV];
+  s->n_big_tier = b->n_big + (b->bigdev_ran ? (uint32_t)T[OT_N_BIG_DEV] : 0u);
   s->n_flagged = (uint32_t)T[OT_N_FLAGGED];
   s->seed_probes = T[OT_SEED_PROBES];
   s->n_count_escapes = b->count16 ? (uint32_t)T[OT_N_ESC] : 0;

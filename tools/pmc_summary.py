@@ -27,7 +27,11 @@ for k_ in seeds[1:]:
     out["(warm-up) " + k_] = out.pop(k_)
 res = {"per_kernel_avg_per_dispatch": out, "round": sys.argv[3] if len(sys.argv) > 3 else None,
        "collected_by": "tools/collect_evidence.sh: rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 20 --warmup 4 "
-                       "--no-cpu --only-step --check 0 --inflight 1 --serial (one pass per counter group)"}
+                       "--no-cpu --only-step --check 0 --inflight 4 --one-at-a-time --serial (one pass per counter group; every launch "
+                       "a kernel alone over one of four distinct target sets, never the set of the launch before it)"
+                       if not (len(sys.argv) > 3 and sys.argv[3].endswith("_hard")) else
+                       "tools/collect_evidence.sh: rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 16 --warmup 4 "
+                       "--no-cpu --profile-hard --inflight 2 (config4_hard, every kernel alone, rotating over its two target sets)"}
 ks = next((v for k_, v in out.items() if k_.startswith("k_seed")), None)
 if ks and "TCC_EA0_RDREQ_sum" in ks:
     r128 = ks.get("TCC_EA0_RDREQ_128B_sum", 0.0)
