@@ -306,7 +306,7 @@ def hard_workload(args, case, dev_index, stream, T, n_fl, profile_only=False):
     sizes = [bq.wait_result() for bq in batches]
     views = [bq.result() for bq in batches]
     tm = []
-    for i in range(args.steps):
+    for i in range(min(args.steps, 40)):
         bq, sq = batches[i % n_fl], streams[i % n_fl]
         bq.run(deliver | kmlib.KM_RUN_TIMED | kmlib.KM_RUN_SERIAL, sq)
         bq.wait_result()
@@ -405,7 +405,9 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="steps of the timed region (x --repeats; 200 x 0.15 ms = 30 ms per repeat: round 3's 40 steps were "
+                         "3.5 ms, shorter than the run-to-run effects they were compared against)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--targets", type=int, default=10000, help="targets per GPU per step")
     ap.add_argument("--length", type=int, default=500)
@@ -713,16 +715,17 @@ def main():
     st0 = tstreams[0]
     device_sync()
     t1 = time.perf_counter()
-    for i in range(args.steps):
+    n_serial = min(args.steps, 40)
+    for i in range(n_serial):
         batch.run(deliver, st0)
         batch.wait_result()
-    serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    serial_ms = (time.perf_counter() - t1) / n_serial * 1e3
     # ---- per-kernel durations (HIP events on the launch stream), averaged over K launches
     # one batch at a time, rotating over the n_fl distinct target sets (each has its own table lines:
     # a set replayed back to back would find part of them in the 256 MiB Infinity Cache)
     def event_times(flags):
         tm = []
-        for i in range(args.steps):
+        for i in range(min(args.steps, 40)):
             bq, sq = batches[i % n_fl], tstreams[i % n_fl]
             bq.run((flags & ~kmlib.KM_RUN_HIPGRAPH) | kmlib.KM_RUN_TIMED, sq)
             bq.wait_result()
