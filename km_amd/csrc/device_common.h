@@ -439,17 +439,11 @@ struct PendingLookup {
   uint64_t S, idx;
   uint4 a0, a1;
   bool valid;
-#ifdef KM_DFS_STAMPS
-  unsigned long long t_key;   // diagnostics: shader clock after the key was computed
-#endif
 };
 __device__ inline void children_issue_wave(const TableView& t, uint64_t X, DirCache* dc,
                                            PendingLookup* p) {
   p->X = X;
   p->g = make_key_wave(t, X & t.pmask);
-#ifdef KM_DFS_STAMPS
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p->t_key)::"memory");
-#endif
   if (p->g.bucket != dc->bucket) {
     const DirPair d = *reinterpret_cast<const DirPair*>(t.dir + p->g.bucket);
     dc->bucket = p->g.bucket; dc->lo = d.lo; dc->hi = d.hi;

@@ -560,21 +560,9 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
 }
 
 // ---------------------------------------------------------------------------- k_dfs
-// Diagnostics build only (-DKM_DFS_STAMPS, tools/dfs_stamps.py): shader-clock time of the
-// sections of a DFS step, summed per wave in scalar registers.
-#ifdef KM_DFS_STAMPS
-#define KM_DFS_STAMP(n)                                                                       \
-  do {                                                                                        \
-    unsigned long long t_;                                                                    \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
-    dfs_acc[n] += (uint32_t)t_ - dfs_prev;                                                    \
-    dfs_prev = (uint32_t)t_;                                                                  \
-    ++dfs_nstamps;                                                                            \
-  } while (0)
-#else
-#define KM_DFS_STAMP(n) do {} while (0)
-#endif
-
+// Diagnostics: -DKM_DFS_COUNTERS (tools/dfs_lifetimes.py with DFS_COUNTERS=1) counts and times, per wave, what the
+// walk did (the KM_DC / KM_DT macros below; nothing in the product build).  KM_SEED_STAMPS in the environment records
+// when a wave started and ended its phases (s_memrealtime, 100 MHz) in the normal build.
 // (the register allocator is told how many waves a SIMD is to hold: 512 / 4 = 128 vector registers)
 #ifndef KM_DFS_WAVES_PER_EU
 #define KM_DFS_WAVES_PER_EU 4
@@ -582,21 +570,10 @@ __global__ __launch_bounds__(SEED_BLOCK) void k_seed(WalkArgs a) {
 template <bool BIG, int K>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES_PER_EU))) void k_dfs(WalkArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-#ifdef KM_DFS_STAMPS
-  uint32_t dfs_entry;
-  const unsigned long long dfs_real0 = __builtin_amdgcn_s_memrealtime();
-  {
-    unsigned long long t_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-    dfs_entry = (uint32_t)t_;
-  }
-#endif
   const uint32_t lane = (uint32_t)lane_id();
-#ifndef KM_DFS_STAMPS
   // diagnostics (KM_SEED_STAMPS in the environment): when this wave started and ended, 100 MHz clock
   unsigned long long life0 = 0, life1 = 0, life2 = 0, lifeB = 0, lifeC = 0;
   if (a.stamps) life0 = __builtin_amdgcn_s_memrealtime();
-#endif
 #ifdef KM_DFS_COUNTERS
   uint32_t dc_nonres = 0, dt_nonres = 0, dc_bigS = 0;
   uint32_t dt_post = 0, dt_pre = 0, dt_chain = 0, dt_tail = 0, dt_pop = 0, dt_seed0 = 0;
@@ -715,9 +692,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   if (lane < nflag) flag0 = flag[lane];
   for (uint32_t w = lane; w <= nwords; w += 64) words[w] = a.packed[wo + w];
   __syncthreads();                                           // the packed words
-#ifndef KM_DFS_STAMPS
   if (a.stamps) lifeB = __builtin_amdgcn_s_memrealtime();
-#endif
   if constexpr (BIG) {
     for (uint32_t s = lane; s < cap; s += 64) { keys[s] = EMPTY; state[s] = 0; }
     for (uint32_t s = lane; s < pcap; s += 64) pos[s] = (pos_t)POS_NONE;
@@ -782,9 +757,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
       ell_pk[q >> 1] |= (q & 1u) ? (v << 16) : v;
     }
   }
-#ifndef KM_DFS_STAMPS
   if (a.stamps) lifeC = __builtin_amdgcn_s_memrealtime();
-#endif
   uint32_t dup = 0;
   // (R1) of the epilogue below — no two of the target's k-mers share their (k-1)-mer prefix, and the
   // last one's suffix is nobody's prefix — is read off this very build: the set hashes a k-mer by its
@@ -864,21 +837,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   uint64_t probes_u = 0;     // wave-uniform
   uint32_t fetch_u = 0;
   if (__any((int)dup)) st = T_REPEAT;
-#ifdef KM_DFS_STAMPS
-  uint32_t dfs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dfs_prev, dfs_t0, dfs_steps = 0;   // 32 bits: few SGPRs
-  uint32_t dfs_general = 0, dfs_runs = 0, dfs_nstamps = 0;
-  uint32_t dfs_loads = 0, dfs_nonres = 0, dfs_maxS = 0, dfs_t_setup;
-  dfs_t0 = dfs_entry;
-  {
-    unsigned long long t_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-    dfs_t_setup = dfs_prev = (uint32_t)t_;
-  }
-#endif
 
-#ifndef KM_DFS_STAMPS
   if (a.stamps) life1 = __builtin_amdgcn_s_memrealtime();
-#endif
   // ---- exact DFS from every flagged seed, in target order ----------------------------
   if (st == T_OK) {
     uint32_t set_count = n_losers;
@@ -905,15 +865,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
         KM_DT(dt_seed0);
         while (true) {
           if (++steps > DFS_STEP_LIMIT) { st = T_INTERNAL; break; }
-          KM_DFS_STAMP(0);                                 // loop control + whatever was not stamped
           if (need_expand) {
             need_expand = false;
             KM_DT0();
             if (n_nodes > a.max_node) { st = T_NODE_LIMIT; break; }
             if (!(pend.valid && pend.X == cur)) children_issue_wave(tab, cur, &dcache, &pend);
-            KM_DFS_STAMP(1);                               // a lookup that had not been requested ahead
             c4 = children_finish_wave(tab, pend, &fetch_u);
-            KM_DFS_STAMP(2);                               // wait for the pair + resolve
             pend.valid = false;
             probes_u += 4;
             KM_DC(dc_gen);
@@ -924,7 +881,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
               ++brk;
               if (brk > a.max_break) mask = 0;
             }
-            KM_DFS_STAMP(8);                               // thresholds
             // the walk most likely continues with the first kept child: request its lookup
             // now, its latency overlaps the bookkeeping of this step
             // (unless that child is a k-mer of the target — for a seed it mostly is, its successor on the target: a
@@ -933,17 +889,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             if (mask && depth + 1 <= a.max_stack &&
                 !__builtin_amdgcn_readfirstlane((int)(ref_index(first_child) != NO_NODE))) {
               children_issue_wave(tab, first_child, &dcache, &pend);
-#ifdef KM_DFS_STAMPS
-              dfs_acc[9] += (uint32_t)pend.t_key - dfs_prev;   // key of the next lookup
-              dfs_prev = (uint32_t)pend.t_key;
-#endif
             }
             KM_DT(dt_post);
-            KM_DFS_STAMP(3);                               // directory word, home pair, request                               // thresholds + key and request of the next lookup
-#ifdef KM_DFS_STAMPS
-            ++dfs_steps;
-            ++dfs_general;
-#endif
           }
           // ---- chain run.  cur has exactly one child left to take.  As long as that keeps
           // being so, only the lookups depend on each other; the node-set probe, the insertion
@@ -1123,15 +1070,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                   bucket_load_wave(tab, rule, p.g.bucket, dcache.lo, dcache.hi, node_hint, &bl, &fetch_u);
                   KM_DC(dc_bload);
                   KM_DT(dt_bload);
-#ifdef KM_DFS_STAMPS
-                  ++dfs_loads;
-                  if (bl.S > dfs_maxS) dfs_maxS = bl.S;
-#endif
                   if (bl.resident) h2 = bucket_find_wave(bl, T);
-#ifdef KM_DFS_STAMPS
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                  KM_DFS_STAMP(11);                        // chain: another bucket (key, directory word, slots, successors)
                 }
                 if (h2.info & SLOT_SINGLE) {
                   c = h2.info & 3u;
@@ -1142,15 +1081,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                   return true;
                 }
                 if (!h2.hit) {
-#ifdef KM_DFS_STAMPS
-                  if (!bl.resident) ++dfs_nonres;
-#endif
                   c4 = children_finish_wave(tab, p, &fetch_u);   // (all zero if the group does not exist)
                   KM_DC(dc_nonres); KM_DT(dt_nonres);
 #ifdef KM_DFS_COUNTERS
                   if (bl.S > dc_bigS) dc_bigS = bl.S;
 #endif
-                  KM_DFS_STAMP(12);                        // chain: lookup in a bucket too large for the lanes
                 } else {
                   c4 = forward_children_wave(tab, x, &dcache, &fetch_u);
                 }
@@ -1161,7 +1096,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
               }
               KM_DT0();
               const uint32_t xm = child_mask(c4, a.ratio, a.nc);
-              KM_DFS_STAMP(13);                            // chain: full expansion
               if (xm != 0 && (xm & (xm - 1)) == 0) {
                 c = (uint32_t)__ffs((int)xm) - 1;
                 cnt = pick4(c4, c);
@@ -1186,15 +1120,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
                 if (lane == n) { rkey = child; rcnt = cnt; }
                 ++n;
                 x = child;
-                KM_DFS_STAMP(0);
                 // ---- the expansion of x: its group among the slots the lanes hold
                 SlotHit h;
                 h.hit = false; h.info = 0;
                 if (bl.resident) h = bucket_find_wave(bl, T);   // (resident implies valid)
-#ifdef KM_DFS_STAMPS
-                if (h.hit) asm volatile("" :: "s"(h.info));
-#endif
-                KM_DFS_STAMP(10);                          // chain: the tag among the lanes
                 if (!(h.info & SLOT_SINGLE)) { was_hit = h.hit; break; }   // (info is 0 on a miss)
                 c = h.info & 3u;
                 cnt = h.info >> 16;
@@ -1217,10 +1146,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
               steps += n;
               KM_DC(dc_runs); KM_DCN(dc_steps, n);
               KM_DT0();
-#ifdef KM_DFS_STAMPS
-              dfs_steps += n;
-              ++dfs_runs;
-#endif
               // ---- booking: first child of the run that is already a node or on the stack
               const bool act = lane < n;
               bool found = false;
@@ -1284,7 +1209,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
               }
               step_sync();
               KM_DT(dt_book);
-              KM_DFS_STAMP(7);                             // booking of a run
             }
           }
           if (mask == 0) {
@@ -1303,7 +1227,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             c4 = f.c4; mask = f.mask; brk = f.brk;
             step_sync();
             KM_DT(dt_unwind);
-            KM_DFS_STAMP(4);                               // unwind to a branch frame
             continue;
           }
           KM_DT0();
@@ -1321,7 +1244,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             if (slot < 0) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
             stt = found ? meta_state(state[slot]) : 0u;
           }
-          KM_DFS_STAMP(5);                                 // node-set probe of the child
           if (found && (stt == ST_NODE || stt == ST_ONSTACK)) {
             // rejoin (or loop): for p in stack: node_data[p] = jf.query(p)
             probes_u += depth;
@@ -1340,7 +1262,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
               step_sync();
             }
             KM_DT(dt_rejoin);
-            KM_DFS_STAMP(6);                               // rejoin: register the stack
           } else if (depth + 1 <= a.max_stack) {
             // __extend(stack + [child], breaks)
             if (!found && set_count + 1 > set_limit) {
@@ -1391,7 +1312,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             need_expand = true;
             step_sync();
             KM_DT(dt_rejoin);
-            KM_DFS_STAMP(7);                               // push
           }
           // else: the child's __extend returns at once (len(stack) > max_stack)
         }
@@ -1429,12 +1349,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   // the four k-mers P+A, P+C, P+G, P+T: no prefix table, no adjacency, no Dijkstra.  Everything else
   // (loops, dead ends, nested bubbles, a bubble cheaper than the reference route, more than
   // EPI_MAX_BUBBLES of them) goes to k_graph through the `left` list, untouched.
-#ifndef KM_DFS_STAMPS
   if (a.stamps) life2 = __builtin_amdgcn_s_memrealtime();
-#endif
   bool answered = false;
   if constexpr (!BIG) {
-    KM_DFS_STAMP(0);
     const uint32_t m = n_nodes, n_walk = n_nodes - n_ref;
     if (a.epi != nullptr && ref_pure && st == T_OK && n_ref >= 2 && n_walk <= 64u * EPI_CHUNKS && m < 0x3FFFu) {
       constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -1699,23 +1616,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
       a.epi->t_refmax[t] = NOT_BARE;
       a.epi->left[atomicAdd(a.epi->n_left, 1u)] = t;
     }
-    KM_DFS_STAMP(14);                                      // epilogue
   }
 
-#ifdef KM_DFS_STAMPS
-  if (a.stamps && lane == 0) {
-    unsigned long long tend;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
-    unsigned long long* o = a.stamps + 32ull * blockIdx.x;
-    for (int q = 0; q < 16; ++q) o[q] = dfs_acc[q];
-    o[16] = dfs_steps; o[17] = (uint32_t)tend - dfs_t0; o[18] = t; o[19] = probes_u;
-    o[20] = dfs_loads; o[21] = dfs_nonres; o[22] = dfs_maxS; o[23] = dfs_general; o[24] = dfs_runs;
-    o[25] = dfs_t_setup - dfs_t0; o[26] = n_nodes - n_ref; o[27] = dfs_nstamps;
-    o[28] = __builtin_amdgcn_s_memrealtime() - dfs_real0;   // 100 MHz
-    o[31] = 0x6466735f7374616dull;                         // record marker
-  }
-#endif
-#ifndef KM_DFS_STAMPS
   if (a.stamps && lane == 0) {
     unsigned long long* o = a.stamps + 32ull * blockIdx.x;
     o[0] = life0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = t; o[3] = n_nodes - n_ref; o[4] = life1; o[5] = life2; o[6] = 0; o[7] = lifeB; o[8] = lifeC;
@@ -1728,7 +1630,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
 #endif
     o[31] = 0x6c6966655f646673ull;
   }
-#endif
   if (lane == 0) {
     a.status[t] = st;
     if constexpr (!BIG) {
