@@ -896,7 +896,10 @@ def test_epilogue_answers_looped_bubbles(k):
     assert flagged == n_t and left <= n_t // 20, (flagged, left)
     cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": k, "canonical": True, "keys": keys, "counts": vals})
     noff, poff = res["node_off"].astype(np.int64), res["path_off"].astype(np.int64)
-    twice = 0
+    def runs_of(path):                                            # maximal stretches of consecutive node indices
+        return 1 + sum(1 for a_, b_ in zip(path, path[1:]) if b_ != a_ + 1)
+
+    twice = twice_oracle = 0
     for t in range(n_t):
         want = ko.analyse_target(seqs[t], "t%d" % t, cpu)
         assert [km.unpack(x, k) for x in res["node_kmer"][noff[t]:noff[t + 1]]] == want["kmers"], t
@@ -904,7 +907,9 @@ def test_epilogue_answers_looped_bubbles(k):
         assert got == [list(p) for p in want["paths"]], t
         assert res["path_min_cov"][poff[t]:poff[t + 1]].tolist() == list(want["min_cov"]), t
         twice += any(int(res["run_off"][p + 1] - res["run_off"][p]) == 4 for p in range(poff[t], poff[t + 1]))
-    assert twice >= 30, twice
+        twice_oracle += any(runs_of(list(p)) == 4 for p in want["paths"])
+    # (how many duplications close their loop is a property of the generator: the count is the oracle's, not a constant)
+    assert twice == twice_oracle and twice_oracle > 0, (twice, twice_oracle)
     b.close()
     db.close()
 
