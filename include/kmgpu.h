@@ -265,6 +265,15 @@ int km_batch_result(km_batch_t* b, km_batch_out_t* view, km_batch_sizes_t* sizes
  * pipelined consumer (km/tools/find_mutation.py:47-58 over successive batches) without an
  * interpreter between the launches. */
 int km_batch_pump(km_batch_t* const* batches, void* const* streams, int n, int steps, int stages);
+/* What the reference logs with -v from inside the walk and the graph, for the last run of `b` (any output may be
+ * NULL): removed_ref_edges[n_targets] / nonref_edges[n_targets] — "Removed %d ref edges." (km/utils/Graph.py:198)
+ * and "%d edges in non-ref edge set." (km/utils/Graph.py:231), in this library's node order (the reference's own
+ * numbers move by one with its hash seed: its `if last_cur` skips whichever node happens to have index 0);
+ * *n_loop_breaks — how often the walk met a k-mer on its stack that was not yet a node ("Broke loop at kmer",
+ * km/utils/MutationFinder.py:160-161); loop_pairs[2 * min(*n_loop_breaks, 4096, loop_cap)] — {target, node index
+ * of that k-mer} in walk order per target.  Waits for the run (and finishes what it left to the host). */
+int km_batch_graph_log(km_batch_t* b, uint32_t* removed_ref_edges, uint32_t* nonref_edges,
+                       uint32_t* n_loop_breaks, uint32_t* loop_pairs, uint32_t loop_cap);
 /* Durations (ms) of the last run (it must have carried KM_RUN_TIMED; zeros otherwise) measured
  * with HIP events on the launch stream:
  * [0] walk stage (k_pack + k_seed + k_dfs), [1] graph stage, [2] walk + graph,

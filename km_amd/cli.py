@@ -61,18 +61,29 @@ CHUNK = 8192          # targets per GPU batch; rows are flushed after every batc
 STREAM_ABOVE = 2_000_000   # catalogs larger than this are printed batch by batch (see main_find_mut)
 
 
-def _verbose_lines(name_seq, raw, t, k, err):
-    """The INFO lines of km/utils/MutationFinder.py:101,126,183-187 that the delivered arrays
-    determine (format "VERBOSE: %(message)s", km/tools/find_mutation.py:20-24).  Node indices
-    follow our canonical order (target k-mers first); the reference's depend on its hash seed."""
+def _verbose_lines(name_seq, raw, t, k, err, glog=None):
+    """The INFO lines of km/utils/MutationFinder.py:101,126,160-161,183-187 and km/utils/Graph.py:198,231, in the
+    reference's order (format "VERBOSE: %(message)s", km/tools/find_mutation.py:20-24).  Node indices and the two
+    edge counts follow our canonical node order (target k-mers first); the reference's depend on its hash seed
+    (its `if last_cur` skips whichever node has index 0: its 'Removed' count is ours or ours - 1).
+    `glog`: Batch.graph_log() of the run."""
+    from . import kmer as km
     seq = name_seq[1]
     n_ref = int(raw["n_ref"][t])
-    n_nodes = n_ref + int(raw["extra_off"][t + 1]) - int(raw["extra_off"][t])
+    x0 = int(raw["extra_off"][t])
+    n_nodes = n_ref + int(raw["extra_off"][t + 1]) - x0
     err.write("VERBOSE: Ref. set contains %d kmers.\n" % n_ref)
+    if glog is not None:
+        for node in glog[2].get(t, ()):                     # where the walk met a k-mer of its own stack
+            mer = seq[node:node + k] if node < n_ref else km.unpack(int(raw["extra_kmer"][x0 + node - n_ref]), k)
+            err.write("VERBOSE: Broke loop at kmer: %s\n" % mer)
     err.write("VERBOSE: k-mer graph contains %d nodes.\n" % (n_nodes + 2))
     err.write("VERBOSE: BigBang=%d, BigCrunch=%d\n" % (n_nodes, n_nodes + 1))
     err.write("VERBOSE: Start kmer %s %d\n" % (seq[:k], 0))
     err.write("VERBOSE: End   kmer %s %d\n" % (seq[n_ref - 1:n_ref - 1 + k], n_ref - 1))
+    if glog is not None:
+        err.write("VERBOSE: Removed %d ref edges.\n" % int(glog[0][t]))
+        err.write("VERBOSE: %d edges in non-ref edge set.\n" % int(glog[1][t]))
     err.write("VERBOSE: %d path(s) from BigBang to BigCrunch.\n"
               % (int(raw["path_off"][t + 1]) - int(raw["path_off"][t])))
 
@@ -164,8 +175,9 @@ def main_find_mut(args, out=None, err=None):
         if hold:
             held.append(sink.getvalue())
         if args.verbose or args.debug:
+            glog = finder.graph_log(len(part))
             for t in range(len(part)):
-                _verbose_lines(part[t], finder.last_raw, t, jf.k, err)
+                _verbose_lines(part[t], finder.last_raw, t, jf.k, err, glog)
         if not hold:
             out.flush()
     release()

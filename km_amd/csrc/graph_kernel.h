@@ -91,6 +91,8 @@ struct GraphArgs {
   uint32_t* t_nruns;         // per target: run records over all its paths
   uint32_t* t_refmax;        // per target: max count over its own k-mers when the result is the bare
                              // reference path (decided by the pure-chain tests), else NOT_BARE
+  uint32_t* t_eremoved;      // per target: reference edges stripped (Graph.py:184-198) / edges left in the non-reference
+  uint32_t* t_enonref;       // edge set (Graph.py:231): the two numbers the reference logs with -v, in our node order
   // Pools are split into POOL_GROUPS equal regions (group = target & 63) so that the
   // bump-allocation atomics of different targets rarely share an address.
   // counters[g*16+0] paths used in group g, [g*16+1] runs used, counters[64*16] overflow flag
@@ -250,6 +252,8 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
       a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi; a.t_nruns[t] = 1;
       a.t_refmax[t] = maxcov;
     }
+    a.t_eremoved[t] = n_ref >= 2 ? n_ref - 1 : 0;           // every chain edge but (0, 1); (source, 0) and it stay
+    a.t_enonref[t] = 2;
     a.need_full[t] = 0;
     a.g_status[t] = T_OK;
   }
@@ -491,6 +495,8 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
             a.t_npaths[t] = 1; a.t_pathbase[t] = (uint32_t)pi; a.t_nruns[t] = 1;
             a.t_refmax[t] = maxcov;
           }
+          a.t_eremoved[t] = n_ref >= 2 ? n_ref - 1 : 0;
+          a.t_enonref[t] = 2;
           a.g_status[t] = T_OK;
         }
       }
@@ -584,6 +590,8 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
         a.p_len[path_base + 1] = (fa + 1) + (m - n_ref) + (n_ref - fb); a.p_mincov[path_base + 1] = scal[6];
         a.t_npaths[t] = 2; a.t_pathbase[t] = (uint32_t)path_base; a.t_nruns[t] = 4;
       }
+      a.t_eremoved[t] = n_ref - 1;                 // the reference chain but its first edge
+      a.t_enonref[t] = (m - n_ref) + 3;            // (source, 0), (0, 1), the bubble's m - n_ref + 1 edges
       a.g_status[t] = T_OK;
     }
   };
@@ -993,12 +1001,15 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
   if (a.dbg == 6) { if (tid == 0) { a.g_status[t] = T_OK; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; } return; }
   // ---- 6. candidate edges and their unique representatives --------------------------
   const uint32_t n_edges = 4 * m + 2;
+  uint32_t my_edges = 0, my_removed = 0;      // -v: edges of the graph / of them stripped (Graph.py:198, 231)
   for (uint32_t e = tid; e < n_edges; e += NT) {
     uint32_t ea, eb;
     bool exists;
     if (e == 4 * m) { ea = src; eb = 0; exists = true; }
     else if (e == 4 * m + 1) { ea = n_ref - 1; eb = snk; exists = true; }
     else { ea = e >> 2; const idx_t v = succ[e]; exists = (v != NONE); eb = v; }
+    my_edges += exists ? 1u : 0u;
+    my_removed += (exists && is_removed(e)) ? 1u : 0u;
     if (!exists || is_removed(e) || !(dist_f[ea] < INF) || !(dist_b[eb] < INF)) continue;
     // representative iff no candidate edge sits at an earlier generating position
     uint32_t x = ea, y = eb, hops = 0;
@@ -1016,7 +1027,10 @@ __global__ __launch_bounds__(GRAPH_THREADS) void k_graph(GraphArgs a0) {
       if (slot < ccap) { cand[2 * slot] = (idx_t)ea; cand[2 * slot + 1] = (idx_t)eb; }
     }
   }
+  for (int o = 32; o > 0; o >>= 1) { my_edges += __shfl_xor(my_edges, o); my_removed += __shfl_xor(my_removed, o); }
+  if (lane == 0) { atomicAdd(&scal[2], my_edges); atomicAdd(&scal[7], my_removed); }
   __syncthreads();
+  if (tid == 0) { a.t_eremoved[t] = scal[7]; a.t_enonref[t] = scal[2] - scal[7]; }
   const uint32_t n_cand = scal[0];
   if (n_cand > ccap) {
     if (tid == 0) { a.g_status[t] = (BIG && !a0.tids_n) ? T_INTERNAL : T_NEEDS_BIG; a.t_npaths[t] = 0; a.t_pathbase[t] = 0; a.t_nruns[t] = 0; hand_to_big(); }

@@ -867,6 +867,7 @@ constexpr uint32_t FAST_EXTRA = 160;          // walk-discovered nodes a fast-ti
 constexpr uint32_t FAST_LDS_LIMIT = 64 * 1024;
 constexpr uint32_t FAST_BCAP_MAX = 512;       // branch frames the fast tier keeps in LDS
 constexpr uint32_t FAST_FCAP_MAX = 4096;      // stack frames per target in the fast tier's scratch
+constexpr uint32_t LOOP_LOG_CAP = 4096;       // loop breaks of a batch kept for km_batch_graph_log (the rest is counted only)
 constexpr uint32_t BIG_DEV_SLOTS = 32;        // targets per run the device's own large tier takes (the rest: the host's)
 constexpr uint64_t BIG_DEV_MAX_BYTES = 1ull << 30;   // ... unless their node storage would exceed this (huge -n)
 
@@ -974,6 +975,8 @@ struct km_batch {
   // the device's own large tier (walk_kernel.h: WalkArgs::big_ctl)
   DevBuf<uint64_t> d_node_base0;
   DevBuf<uint32_t> d_big_ctl, d_big_walk, d_big_graph;
+  // -v (km_batch_graph_log): reference edges stripped / edges kept per target, the walk's loop breaks
+  DevBuf<uint32_t> d_t_eremoved, d_t_enonref, d_loop_list, d_loop_ctl;
   DevBuf<unsigned char> d_bigdev_walk_ws, d_bigdev_graph_ws;
   uint32_t big_entry = 0;              // nodes per slot of the region (0: tier off)
   uint64_t big_region = 0;             // its first node (the region sits in front of the fast-tier layout)
@@ -1080,6 +1083,11 @@ extern "C" int km_batch_create(kmjf_t* h, const km_params_t* params, uint32_t ma
   A(b->d_big_ctl.alloc(8));
   A(b->d_big_walk.alloc(BIG_DEV_SLOTS));
   A(b->d_big_graph.alloc(BIG_DEV_SLOTS));
+  A(b->d_t_eremoved.alloc(max_targets));
+  A(b->d_t_enonref.alloc(max_targets));
+  A(b->d_loop_list.alloc(2ull * LOOP_LOG_CAP));
+  A(b->d_loop_ctl.alloc(4));
+  if (rc == KM_OK && hipMemset(b->d_loop_ctl.p, 0, 16) != hipSuccess) rc = fail(KM_E_HIP, "hipMemset failed");
   if (rc == KM_OK && hipMemset(b->d_big_ctl.p, 0, 32) != hipSuccess) rc = fail(KM_E_HIP, "hipMemset failed");
   A(b->d_node_kmer.alloc(pool));
   A(b->d_node_cnt.alloc(pool));
@@ -1140,6 +1148,7 @@ extern "C" int km_batch_destroy(km_batch_t* b) {
   b->d_big_ids.release(); b->d_big_ws.release(); b->d_tref.release(); b->d_frames.release(); b->d_stamps.release();
   b->d_node_base0.release(); b->d_big_ctl.release(); b->d_big_walk.release(); b->d_big_graph.release();
   b->d_bigdev_walk_ws.release(); b->d_bigdev_graph_ws.release();
+  b->d_t_eremoved.release(); b->d_t_enonref.release(); b->d_loop_list.release(); b->d_loop_ctl.release();
   for (int i = 0; i < 7; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   if (b->d_out) (void)hipFree(b->d_out);
   if (b->h_out) (void)hipHostFree(b->h_out);
@@ -1288,6 +1297,11 @@ static void fill_walk_args(km_batch* b, WalkArgs& a) {
   a.big_entry = b->big_entry;
   a.big_region = b->big_region;
   a.big_prep = 0;
+  a.loop_list = b->d_loop_list.p;
+  a.loop_ctl = b->d_loop_ctl.p;
+  a.loop_cap = LOOP_LOG_CAP;
+  a.t_eremoved = b->d_t_eremoved.p;
+  a.t_enonref = b->d_t_enonref.p;
   a.n_nodes = b->d_n_nodes.p;
   a.n_ref = b->d_n_ref.p;
   a.status = b->d_status.p;
@@ -1332,6 +1346,8 @@ static void fill_graph_args(km_batch* b, GraphArgs& g) {
   g.t_pathbase = b->d_pathbase.p;
   g.t_nruns = b->d_t_nruns.p;
   g.t_refmax = b->d_t_refmax.p;
+  g.t_eremoved = b->d_t_eremoved.p;
+  g.t_enonref = b->d_t_enonref.p;
   g.counters = b->d_counters.p;
   g.path_pool = b->path_pool;
   g.run_pool = b->run_pool;
@@ -1422,6 +1438,7 @@ static void fast_geometry(km_batch* b) {
     e.p_mincov = ga.p_mincov; e.r_start = ga.r_start; e.r_len = ga.r_len;
     e.g_status = ga.g_status; e.t_npaths = ga.t_npaths; e.t_pathbase = ga.t_pathbase; e.t_nruns = ga.t_nruns;
     e.t_refmax = ga.t_refmax;
+    e.t_eremoved = ga.t_eremoved; e.t_enonref = ga.t_enonref;
     e.left = b->d_left.p; e.n_left = b->d_nflagged.p + 2;
     if (!b->epi_valid || memcmp(&e, &b->h_epi, sizeof e) != 0) {
       if (hipMemcpy(b->d_epi.p, &e, sizeof e, hipMemcpyHostToDevice) == hipSuccess) { b->h_epi = e; b->epi_valid = true; }
@@ -2289,6 +2306,34 @@ extern "C" int km_probe_bench(kmjf_t* h, const uint64_t* kmers, uint64_t n, int 
 
 // Diagnostics: the device counters of the last run — [0] flagged targets (k_seed), [1] unflagged
 // targets k_graph_pure handed to k_graph, [2] flagged targets the epilogue of k_dfs left to k_graph.
+// What the reference logs with -v from inside the walk and the graph (km/utils/MutationFinder.py:160-161,
+// km/utils/Graph.py:198, 231), for the last run: per target the reference edges stripped and the edges kept, and the
+// walk's loop breaks as {target, node index} pairs in walk order.  Any output may be NULL.
+extern "C" int km_batch_graph_log(km_batch_t* b, uint32_t* removed_ref_edges, uint32_t* nonref_edges,
+                                  uint32_t* n_loop_breaks, uint32_t* loop_pairs, uint32_t loop_cap) {
+  if (!b) return fail(KM_E_ARG, "null argument");
+  if (!b->ran_walk) return fail(KM_E_STATE, "no run to report on");
+  if (b->deliver_pending || b->result_ready) {          // a delivered run: finish it (large tier, pools) first
+    int rc = finish_result(b, false);
+    if (rc != KM_OK) return rc;
+  } else {
+    int rc = km_batch_sync(b);
+    if (rc != KM_OK) return rc;
+  }
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t st = b->last_stream;
+  HIPCHK(hipStreamSynchronize(st));
+  const uint32_t n = b->n_targets;
+  if (removed_ref_edges && n) HIPCHK(hipMemcpy(removed_ref_edges, b->d_t_eremoved.p, 4ull * n, hipMemcpyDeviceToHost));
+  if (nonref_edges && n) HIPCHK(hipMemcpy(nonref_edges, b->d_t_enonref.p, 4ull * n, hipMemcpyDeviceToHost));
+  uint32_t n_loops = 0;
+  if (n) HIPCHK(hipMemcpy(&n_loops, b->d_loop_ctl.p, 4, hipMemcpyDeviceToHost));
+  if (n_loop_breaks) *n_loop_breaks = n_loops;
+  const uint32_t have = std::min<uint32_t>(std::min<uint32_t>(n_loops, LOOP_LOG_CAP), loop_cap);
+  if (loop_pairs && have) HIPCHK(hipMemcpy(loop_pairs, b->d_loop_list.p, 8ull * have, hipMemcpyDeviceToHost));
+  return KM_OK;
+}
+
 extern "C" int km_batch_debug_counts(km_batch_t* b, uint32_t* out4) {
   if (!b || !out4) return fail(KM_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));

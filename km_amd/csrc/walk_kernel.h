@@ -78,6 +78,8 @@ struct EpiArgs {
   uint32_t* t_refmax;
   uint32_t* left;         // flagged targets the epilogue did not answer: k_graph's work list
   uint32_t* n_left;       // device counter
+  uint32_t* t_eremoved;   // per target: reference edges the graph stage strips / edges it keeps — what the reference
+  uint32_t* t_enonref;    // logs with -v (km/utils/Graph.py:198, 231), in our node order
 };
 constexpr uint32_t EPI_CHUNKS = 3;         // walk-discovered nodes the epilogue looks at: up to 192 (fast tier: 160)
 constexpr uint32_t EPI_MAX_BUBBLES = 8;    // more than that: left to k_graph
@@ -139,6 +141,14 @@ struct WalkArgs {
   uint32_t big_entry;
   uint64_t big_region;
   uint32_t big_prep;               // k_dfs<BIG>: this launch works off big_walk and re-homes its targets itself
+  // -v: where the walk met a k-mer that is on its stack and not yet a node ('Broke loop at kmer', km/utils/
+  // MutationFinder.py:160-161): pairs {target, node index of that k-mer}, in walk order per target; loop_ctl[0] counts
+  // them (the list holds loop_cap pairs, what does not fit is counted only).  t_eremoved / t_enonref: see EpiArgs.
+  uint32_t* loop_list;
+  uint32_t* loop_ctl;
+  uint32_t loop_cap;
+  uint32_t* t_eremoved;
+  uint32_t* t_enonref;
   uint32_t* n_nodes;
   uint32_t* n_ref;
   uint32_t* status;
@@ -354,6 +364,9 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack(WalkArgs a) {
     a.tflag[t] = 0;
     a.node_base[t] = nbase;                  // (a large-tier pass of the last run may have re-homed the target)
     a.node_cap[t] = n_ref + a.fast_extra;
+    a.t_eremoved[t] = 0;
+    a.t_enonref[t] = 0;
+    if (t == 0) a.loop_ctl[0] = 0;
     if (t == 0 && a.big_ctl) { a.big_ctl[0] = 0; a.big_ctl[1] = 0; }
     if (t == 0) { a.n_flagged[0] = 0; a.n_flagged[1] = 0; a.n_flagged[2] = 0; }   // [1]: targets k_graph_pure hands to k_graph, [2]: those k_dfs's epilogue leaves to it
   }
@@ -605,6 +618,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
     n_ref = a.n_ref[t];
     nb = a.node_base[t];
     node_cap = a.node_cap[t];
+    // (whatever loop breaks the fast tier's abandoned attempt at this target logged are void: a marker says so)
+    if (lane == 0 && a.status[t] == T_NEEDS_BIG) {
+      const uint32_t at = atomicAdd(&a.loop_ctl[0], 1u);
+      if (at < a.loop_cap) { a.loop_list[2 * at] = t; a.loop_list[2 * at + 1] = 0xFFFFFFFFu; }
+    }
     if (a.big_prep) {
       // the device's own large tier: slot blockIdx.x of the region; the seed kernel's counts move there
       const uint64_t need = (uint64_t)max(n_ref, a.max_node + a.max_stack) + 1;
@@ -1247,6 +1265,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
           if (found && (stt == ST_NODE || stt == ST_ONSTACK)) {
             // rejoin (or loop): for p in stack: node_data[p] = jf.query(p)
             probes_u += depth;
+            if (stt == ST_ONSTACK) {
+              // a loop: the child is on the stack and not yet a node — the reference logs it (-v).  It becomes a
+              // node right below: its index follows from its stack position (the frame whose set slot this is)
+              uint32_t jc = 0xFFFFFFFFu;
+              mem_sync();
+              for (uint32_t j0 = reg; j0 < depth && jc == 0xFFFFFFFFu; j0 += 64) {       // wave-uniform
+                const uint32_t j = j0 + lane;
+                const unsigned long long hit_ = __ballot(j < depth && fs[j] == (uint32_t)slot);
+                if (hit_) jc = j0 + (uint32_t)__ffsll((long long)hit_) - 1;
+              }
+              if (lane == 0 && jc != 0xFFFFFFFFu) {
+                const uint32_t at = atomicAdd(&a.loop_ctl[0], 1u);
+                if (at < a.loop_cap) { a.loop_list[2 * at] = t; a.loop_list[2 * at + 1] = n_nodes + (jc - reg); }
+              }
+            }
             if (reg < depth) {
               const uint32_t add = depth - reg;
               if (n_nodes + add > node_cap) { st = BIG ? T_INTERNAL : T_NEEDS_BIG; break; }
@@ -1589,6 +1622,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
             ea.t_npaths[t] = (uint32_t)want_paths; ea.t_pathbase[t] = (uint32_t)pb; ea.t_nruns[t] = (uint32_t)want_runs;
             ea.t_refmax[t] = n_bub ? NOT_BARE : ref_max;
             ea.g_status[t] = T_OK;
+            // (the sink tree from node 0 is the reference chain: every one of its edges but the first is stripped;
+            // what stays are the two of the caps' side — (source, 0), (0, 1) — and the bubbles' own)
+            ea.t_eremoved[t] = n_ref - 1;
+            ea.t_enonref[t] = 2u + n_walk + n_bub + n_loop;
           }
           if (lane < n_bub) {
             const uint64_t r0 = rb + 1 + 3ull * lane, p0 = pb + 1 + lane;

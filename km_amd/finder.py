@@ -53,6 +53,11 @@ class BatchFinder:
             self._cap = cap
         return self._batch
 
+    def graph_log(self, n_targets):
+        """What the reference logs with -v from inside the walk and the graph, for the last batch
+        (km_batch_graph_log): (removed_ref_edges, nonref_edges, {target: [loop node, ...]}, n_loop_breaks)."""
+        return self._batch.graph_log(n_targets)
+
     def run_raw(self, seqs, stream=None):
         """Walk + path search for a list of sequences; returns the raw result dict."""
         b = self._ensure(len(seqs), sum(len(s) for s in seqs))

@@ -31,7 +31,7 @@ SYMBOLS = [
     "kmjf_upload", "kmjf_upload_from_device", "kmjf_broadcast", "kmjf_query_batch", "kmjf_children_batch",
     "kmjf_query_batch_dev", "kmjf_children_batch_dev", "km_batch_create", "km_batch_destroy",
     "km_batch_set_targets", "km_batch_set_targets_dev", "km_batch_run", "km_batch_sync",
-    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_pump", "km_batch_debug_stamps", "km_batch_debug_counts",
+    "km_batch_sizes", "km_batch_fetch", "km_batch_result", "km_batch_timings", "km_batch_graph_log", "km_batch_pump", "km_batch_debug_stamps", "km_batch_debug_counts",
     "km_device_sync", "km_device_copy_GBs", "km_probe_bench",
     "km_report_rows", "km_report_free", "km_strerror", "km_last_error",
     "km_device_count", "km_stream_create", "km_stream_destroy", "km_version",
@@ -191,6 +191,7 @@ def load():
         "km_batch_fetch": [vp, C.POINTER(BatchOut)],
         "km_batch_result": [vp, C.POINTER(BatchOut), C.POINTER(BatchSizes)],
         "km_batch_timings": [vp, C.POINTER(C.c_float)],
+        "km_batch_graph_log": [vp, vp, vp, C.POINTER(u32), vp, u32],
         "km_batch_pump": [C.POINTER(vp), C.POINTER(vp), i32, i32, i32],
         "km_batch_debug_stamps": [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)],
         "km_batch_debug_counts": [vp, C.POINTER(C.c_uint32)],
@@ -445,6 +446,26 @@ class Batch:
         ms = (C.c_float * 8)()
         check(self._lib.km_batch_timings(self._b, ms))
         return tuple(float(x) for x in ms)
+
+    def graph_log(self, n_targets):
+        """What the reference logs with -v from inside the walk and the graph (km_batch_graph_log): per target the
+        reference edges stripped and the edges kept, and per target the node indices at which the walk broke a
+        loop, in walk order.  -> (removed uint32[n], nonref uint32[n], {target: [node index, ...]}, n_loop_breaks)."""
+        n = int(n_targets)
+        removed = np.zeros(max(1, n), dtype=np.uint32)
+        nonref = np.zeros(max(1, n), dtype=np.uint32)
+        cap = 4096
+        pairs = np.zeros(2 * cap, dtype=np.uint32)
+        n_loops = C.c_uint32(0)
+        check(self._lib.km_batch_graph_log(self._b, ptr(removed), ptr(nonref), C.byref(n_loops), ptr(pairs), cap))
+        loops = {}
+        for t, node in pairs[:2 * min(cap, n_loops.value)].reshape(-1, 2).tolist():
+            if node == 0xFFFFFFFF:               # the large tier starts this target's walk over
+                loops.pop(t, None)
+            else:
+                loops.setdefault(t, []).append(node)
+        n_real = sum(len(v) for v in loops.values())
+        return removed[:n], nonref[:n], loops, n_real
 
     def debug_counts(self):
         """(flagged targets, unflagged ones handed to k_graph, flagged ones the epilogue of k_dfs left to k_graph)."""

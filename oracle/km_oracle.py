@@ -107,9 +107,10 @@ def ref_kmers(seq, name, k):
     return out
 
 
-def walk(ref_mers, db, max_stack=500, max_break=10, max_node=10000):
+def walk(ref_mers, db, max_stack=500, max_break=10, max_node=10000, loops=None):
     """Register the target's k-mers, then depth-first extend from each of them.
-    Returns the ordered {kmer: count} node dict."""
+    Returns the ordered {kmer: count} node dict.  `loops` (a list): the k-mers at which the
+    reference logs 'Broke loop at kmer' (MutationFinder.py:160-161), in walk order."""
     nodes = {}
     for mer in ref_mers:                       # canonical order: target order
         nodes[mer] = db.query(mer)
@@ -126,6 +127,8 @@ def walk(ref_mers, db, max_stack=500, max_break=10, max_node=10000):
                 return
         for kid in kids:
             if kid in nodes or kid in stack:
+                if loops is not None and kid in stack and kid not in nodes:
+                    loops.append(kid)
                 for mer in stack:
                     nodes[mer] = db.query(mer)
             else:
@@ -210,16 +213,22 @@ def enumerate_paths(edges, before, after, source, sink):
     return sorted(found)                       # canonical order (see header)
 
 
-def graph_paths(kmers, n_ref):
+def graph_paths(kmers, n_ref, stats=None):
     """All source->sink paths through a non-reference edge, caps stripped.
-    `kmers`: node list (ref k-mers first, in target order) WITHOUT caps."""
+    `kmers`: node list (ref k-mers first, in target order) WITHOUT caps.  `stats` (a dict): what the
+    reference logs on the way — 'Removed %d ref edges.' (Graph.py:198) and '%d edges in non-ref edge
+    set.' (Graph.py:231) — in OUR node order (the reference's own numbers move by one with its hash
+    seed: `if last_cur` skips whichever node happens to have index 0)."""
     names = list(kmers) + [SOURCE, SINK]
     n = len(names)
     ref_index = list(range(n_ref))
     w, edges = build_graph(names, ref_index, 0, n_ref - 1)
     before = dijkstra_prev(w, n - 2)
     after = dijkstra_prev(w.transpose(), n - 1)
-    strip_ref_edges(edges, before, after, n - 2)
+    removed = strip_ref_edges(edges, before, after, n - 2)
+    if stats is not None:
+        stats["removed_ref_edges"] = removed
+        stats["nonref_edges"] = len(edges)
     return [p[1:-1] for p in enumerate_paths(edges, before, after, n - 2, n - 1)]
 
 
@@ -381,13 +390,16 @@ def analyse_target(seq, name, db, max_stack=500, max_break=10, max_node=10000):
     mers = ref_kmers(seq, name, k)
     assert len(mers)
     p0 = db.probes
-    nodes = walk(mers, db, max_stack, max_break, max_node)
+    loops = []
+    nodes = walk(mers, db, max_stack, max_break, max_node, loops)
     probes = db.probes - p0
     kmers = list(nodes.keys())
     counts = list(nodes.values())
-    paths = graph_paths(kmers, len(mers))
+    stats = {}
+    paths = graph_paths(kmers, len(mers), stats)
     return {"name": name, "k": k, "n_ref": len(mers), "kmers": kmers, "counts": counts,
-            "paths": paths, "probes": probes,
+            "paths": paths, "probes": probes, "loop_kmers": loops,
+            "removed_ref_edges": stats["removed_ref_edges"], "nonref_edges": stats["nonref_edges"],
             "min_cov": [min(counts[i] for i in p) for p in paths]}
 
 

@@ -118,6 +118,38 @@ elif job["kind"] == "walk":
                     "path_seqs": paths,
                     "path_min_cov": [mincov[s] for s in paths]})
     out = {"targets": res}
+elif job["kind"] == "graphlog":
+    # the INFO records the reference logs from inside the walk and the graph (km/utils/MutationFinder.py:161,
+    # km/utils/Graph.py:198,231): how many reference edges it strips, how many edges stay, where it breaks a loop
+    import logging, re
+
+    class Grab(logging.Handler):
+        def __init__(self):
+            super().__init__(logging.INFO)
+            self.msgs = []
+
+        def emit(self, rec):
+            self.msgs.append(rec.getMessage())
+
+    grab = Grab()
+    root = logging.getLogger()                 # the reference logs through the root logger (`import logging as log`)
+    root.setLevel(logging.INFO)
+    root.addHandler(grab)
+    jf = Jellyfish(job["db"], cutoff=job.get("ratio", 0.05), n_cutoff=job.get("count", 5))
+    res = []
+    for t in job["targets"]:
+        name = os.path.splitext(os.path.basename(t))[0]
+        seqs, _ = uc.file_2_seq(t)
+        ref = us.RefSeq("".join(seqs), name, jf.k)
+        grab.msgs = []
+        f = umf.MutationFinder(ref, jf, job.get("steps", 500), job.get("branchs", 10), job.get("nodes", 10000))
+        f.graph_analysis()
+        removed = [int(re.match(r"Removed (\d+) ref edges", m).group(1)) for m in grab.msgs if m.startswith("Removed ")]
+        nonref = [int(re.match(r"(\d+) edges in non-ref edge set", m).group(1)) for m in grab.msgs if "edges in non-ref edge set" in m]
+        loops = [m.split(": ", 1)[1] for m in grab.msgs if m.startswith("Broke loop at kmer")]
+        res.append({"name": name, "removed_ref_edges": removed, "nonref_edges": nonref, "loop_kmers": loops,
+                    "num_k": f.num_k})
+    out = {"targets": res}
 elif job["kind"] == "children":
     jf = Jellyfish(job["db"], cutoff=job.get("ratio", 0.05), n_cutoff=job.get("count", 5))
     res = []
@@ -312,6 +344,35 @@ def main():
             gold["exclu"].append({"target": tfa, "exclu": "./data/jf/" + excl, "find_report": rep})
         with open(os.path.join(args.out, "sample_matrix.json"), "w") as fh:
             json.dump(gold, fh, indent=1)
+
+    # ---- 6. the -v lines of the walk and the graph: stripped reference edges, edges left, loop breaks
+    if on("graphlog"):
+        sys.path.insert(0, REPO)
+        from km_amd import synth
+        gold = {"cases": []}
+        for db in DBS:
+            job = {"kind": "graphlog", "targets": ["./data/catalog/GRCh38/" + f for f in CATALOG], "db": "./data/jf/" + db}
+            o, st, outs = r.stable(job, seeds=[0, 1, 2])
+            for ti, t in enumerate(o["targets"]):
+                t["loop_kmers_by_seed"] = [sorted(x["targets"][ti]["loop_kmers"]) for x in outs]
+            gold["cases"].append({"db": job["db"], "targets_fa": job["targets"], "stable": st, "targets": o["targets"]})
+            print("graphlog", db, "stable" if st else "UNSTABLE",
+                  [(t["name"][:6], t["removed_ref_edges"], t["nonref_edges"], len(t["loop_kmers"])) for t in o["targets"]])
+        for spec in synth.GOLDEN_SPECS:
+            with tempfile.TemporaryDirectory() as td:
+                fas, dbp, meta = synth.write_case(td, **spec)
+                job = {"kind": "graphlog", "targets": fas, "db": dbp}
+                job.update(spec.get("params", {}))
+                if spec.get("params", {}).get("nodes", 10000) < 1000:
+                    continue                                   # (the node-limit case exits before the graph)
+                o, st, outs = r.stable(job, seeds=[0, 1, 2], cwd=td)
+                for ti, t in enumerate(o["targets"]):
+                    t["loop_kmers_by_seed"] = [sorted(x["targets"][ti]["loop_kmers"]) for x in outs]
+                gold["cases"].append({"spec": spec, "input_md5": meta["md5"], "stable": st, "targets": o["targets"]})
+                print("graphlog synth", spec.get("name"), "stable" if st else "UNSTABLE",
+                      sum(len(t["loop_kmers"]) for t in o["targets"]), "loop breaks")
+        with open(os.path.join(args.out, "graph_log.json"), "w") as fh:
+            json.dump(gold, fh)
 
     # ---- 4. synthetic slices (generator: km_amd/synth.py) -------------------------
     if on("synth"):

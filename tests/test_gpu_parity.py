@@ -1088,6 +1088,11 @@ def test_cli_verbose_and_graphical(capsys):
     lines[6] = "#verbose:True"
     assert cap.out.splitlines()[:-1] == lines
     assert "VERBOSE: Ref. set contains 50 kmers." in cap.err and "VERBOSE: k-mer graph contains 82 nodes." in cap.err
+    # the two lines of the graph (Graph.py:198, 231), in our node order: the reference printed 48 / 3 + the bubble's edges
+    # for this target under the generator's seeds (tests/golden/graph_log.json), i.e. ours or ours - 1 stripped edges
+    assert "VERBOSE: Removed 49 ref edges." in cap.err and "edges in non-ref edge set." in cap.err
+    order = [l for l in cap.err.splitlines() if l.startswith("VERBOSE: ")]
+    assert order.index("VERBOSE: Removed 49 ref edges.") > [i for i, l in enumerate(order) if l.startswith("VERBOSE: End   kmer")][0]
     args = p.parse_args(["-g"] + case["targets"] + [case["db"]])
     with pytest.raises(SystemExit, match="not supported"):
         cli.main_find_mut(args)
@@ -1642,4 +1647,69 @@ def test_real_size_sample_500M_kmers():
         n_multi += len(got) > 1
     assert n_multi > 100
     b.close()
+    db.close()
+
+
+def test_graph_log_matches_the_oracle_and_the_reference():
+    """km_batch_graph_log: what the reference logs with -v from inside the walk and the graph — reference edges
+    stripped, edges kept (Graph.py:198, 231), k-mers at which the walk broke a loop (MutationFinder.py:160-161).
+    Against the oracle on the catalog and on walks that circle tandem repeats; against the reference's own log
+    (tests/golden/graph_log.json, written by make_golden.py from the imported reference): its stripped-edge count is
+    ours or ours - 1 (its `if last_cur` skips whichever node its hash seed gave index 0), its loop k-mers are ours."""
+    gold = _load("graph_log.json")["cases"]
+    for case in gold[:5]:
+        dbp = case["db"]
+        jf = Jellyfish(dbp, cutoff=0.05, n_cutoff=5, device=0)
+        cpu = ko.KmerDB(dbp, 0.05, 5)
+        finder = BatchFinder(jf)
+        targets = [(t["name"], ko.read_fasta_concat(fa)) for t, fa in zip(case["targets"], case["targets_fa"])]
+        raw = finder.run_raw([t[1] for t in targets])
+        removed, nonref, loops, n_loops = finder.graph_log(len(targets))
+        for ti, (name, seq) in enumerate(targets):
+            want = ko.analyse_target(seq, name, cpu)
+            assert int(removed[ti]) == want["removed_ref_edges"] and int(nonref[ti]) == want["nonref_edges"], (dbp, name)
+            ref_t = case["targets"][ti]
+            assert ref_t["removed_ref_edges"][0] in (int(removed[ti]), int(removed[ti]) - 1), (dbp, name)
+            assert ref_t["removed_ref_edges"][0] + ref_t["nonref_edges"][0] == int(removed[ti]) + int(nonref[ti])
+            assert ti not in loops and not want["loop_kmers"] and not ref_t["loop_kmers"]
+        jf.db.close()
+    # walks that circle tandem repeats (the k-mers they close on are walk-discovered nodes), a multi-variant batch
+    rng = np.random.default_rng(31)
+
+    def rand_seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    k = 31
+    reads, targets = [], []
+    for unit in ("CAG", "ACGTT", "GATTACA"):
+        tgt = rand_seq(k + 5) + unit * 2 + rand_seq(k + 7)
+        cut = k + 5 + 2 * len(unit)
+        reads += [(tgt, 50), (tgt[:cut] + unit * (k // len(unit) + 6), 30)]
+        targets.append(("rep_" + unit, tgt))
+    case = synth.make_case(n_targets=150, length=300, k=k, n_keys=60_000, seed=515, variant_frac=0.9,
+                           variants_per_target=(1, 3), hom_frac=0.2, branch_noise_frac=0.03, exact_pad=False)
+    keys0, counts0 = _db_from_reads(reads, k, None)
+    keys = np.concatenate([keys0, case["keys"]])
+    counts = np.concatenate([counts0, case["counts"]])
+    keys, first = np.unique(keys, return_index=True)
+    counts = counts[first]
+    targets += [(n_, km.decode(r_)) for n_, r_ in zip(case["names"], case["targets"])]
+    db = kmlib.Database.from_records(keys, counts, k).upload(0)
+    jf = Jellyfish("mem.jf", cutoff=0.05, n_cutoff=5, db=db)
+    cpu = ko.KmerDB(None, cutoff=0.05, n_cutoff=5, records={"k": k, "canonical": True, "keys": keys, "counts": counts})
+    finder = BatchFinder(jf)
+    raw = finder.run_raw([t[1] for t in targets])
+    removed, nonref, loops, n_loops = finder.graph_log(len(targets))
+    noff = raw["node_off"].astype(np.int64)
+    seen_loops = 0
+    for ti, (name, seq) in enumerate(targets):
+        try:
+            want = ko.analyse_target(seq, name, cpu)
+        except ValueError:
+            continue
+        assert int(removed[ti]) == want["removed_ref_edges"] and int(nonref[ti]) == want["nonref_edges"], name
+        got = [km.unpack(int(raw["node_kmer"][noff[ti] + n]), k) for n in loops.get(ti, [])]
+        assert got == want["loop_kmers"], name
+        seen_loops += len(got)
+    assert seen_loops >= 3 and n_loops == sum(len(v) for v in loops.values())
     db.close()
