@@ -48,6 +48,7 @@ enum {
   OT_PROBES, OT_FETCHES, OT_SEED_PROBES, OT_N_FLAGGED, OT_SERIAL,
   OT_N_ESC = 24,        // 16-bit counts: counts >= 65535 met so far (k_out_scan zeroes it, k_out_pack adds)
   OT_N_BIG_DEV = 25,    // targets the device's own large tier took in this run (walk_kernel.h: WalkArgs::big_ctl)
+  OT_N_GRAPH_LIST = 26, // entries of k_graph's work list in this run (what the epilogue of k_dfs left + what k_graph_pure handed over)
   OT_WORDS = 32
 };
 constexpr uint32_t OUT_ESC_CAP = 2048;   // exact counts the escape list of one delivery holds
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(64) void k_out_pack(OutArgs a) {
     T[OT_N_FLAGGED] = *a.n_flagged;
     T[OT_SERIAL] = a.serial;
     for (int q = OT_SERIAL + 1; q < OT_WORDS; ++q) if (q != OT_N_ESC) T[q] = 0;
+    T[OT_N_GRAPH_LIST] = (unsigned long long)a.n_flagged[1] + a.n_flagged[2];
     if (a.big_ctl) T[OT_N_BIG_DEV] = min(a.big_ctl[0], a.big_slots);      // (walks; a target only its graph pass took is not counted, as on the host's path)
     a.o_node_off[n] = tot[0]; a.o_extra_off[n] = tot[1]; a.o_path_off[n] = (uint32_t)tot[2];
   }

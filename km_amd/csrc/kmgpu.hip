@@ -986,6 +986,11 @@ struct km_batch {
   // takes the host's path, as every one used to; KM_BIG_DEVICE=1 arms the tier from the first run)
   bool bigdev_armed = false;
   bool bigdev_ran = false;             // the last run launched it
+  // k_graph's grid follows what the last delivery of this batch reported for its work list (4x + 64 blocks, at most
+  // the default): with nothing left to it — the headline batch — its 1 250 blocks were a launch of 320 000 threads
+  // that read two words each, 8.6 us alone and 31 us inside the pipeline.  More entries than blocks go to the
+  // large tier (graph_kernel.h), and the next run's grid is larger.
+  uint32_t graph_list_seen = 0xFFFFFFFFu;   // (nothing seen yet: the default grid)
   // host mirrors after sync
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
   unsigned long long h_overflow = 0;
@@ -1460,7 +1465,9 @@ static void launch_graph(km_batch* b, hipStream_t st, const GraphArgs& ga) {
   // the rest to the large tier (graph_kernel.h).
   uint32_t grid = b->n_targets;
   if (ga.work_list && ga.dfs_answers) {
-    const uint32_t cap = knobs().graph_grid ? knobs().graph_grid : std::max<uint32_t>(1024u, b->n_targets / 8);
+    uint32_t cap = knobs().graph_grid ? knobs().graph_grid : std::max<uint32_t>(1024u, b->n_targets / 8);
+    if (!knobs().graph_grid && b->graph_list_seen != 0xFFFFFFFFu)
+      cap = std::min<uint32_t>(cap, (uint32_t)std::min<uint64_t>(4ull * b->graph_list_seen + 64, 0x7FFFFFFFull));
     grid = std::min<uint32_t>(grid, cap);
   }
   if (ga.k == 31) hipLaunchKernelGGL((k_graph<false, 31>), dim3(grid), dim3(GRAPH_THREADS), b->graph_lds, st, ga);
@@ -2073,6 +2080,12 @@ static int finish_result(km_batch* b, bool need_full) {
     }
     if (T[OT_SERIAL] != b->serial) return fail(KM_E_HIP, "delivery buffer out of step");
     const unsigned long long nh = T[OT_NEEDS_HOST];
+    if (b->ran_graph && b->graph_mode == 0) {
+      const uint32_t seen = (uint32_t)std::min<unsigned long long>(T[OT_N_GRAPH_LIST], 0x7FFFFFFFull);
+      // (a captured step holds its grid: it is dropped when the list outgrows a quarter of it or shrinks to a 16th)
+      if (b->gexec && b->graph_list_seen != 0xFFFFFFFFu && (seen > 2 * b->graph_list_seen + 16 || 16 * seen + 64 < b->graph_list_seen)) drop_graph(b);
+      b->graph_list_seen = seen;
+    }
     if (b->big_entry && !b->bigdev_armed && ((nh & 1ull) || T[OT_N_BIG_DEV])) {
       b->bigdev_armed = true;              // from the next run on, the device's own large tier is launched
       drop_graph(b);                       // (a captured step does not contain its launches)

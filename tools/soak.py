@@ -25,6 +25,8 @@ for rd in range(rounds):
     k = int(rng.choice([21, 25, 31, 31, 31, 32]))
     n = int(rng.choice([600, 1500]))
     length = int(rng.choice([200, 350, 500]))
+    if os.environ.get("SOAK_LONG"):                 # targets beyond the LDS tier: every one of them through the large tier
+        n, length = int(rng.choice([24, 70])), int(rng.choice([2200, 3100]))
     cov = (20, 300) if rng.random() < 0.3 else (50, 2000)
     multi = rng.random() < 0.4                      # several variants per target, homozygous ones, dead-end branches
     heavy = rng.random() < 0.15 or bool(os.environ.get("SOAK_HEAVY"))   # 3-5 tandem duplications: the large tier
