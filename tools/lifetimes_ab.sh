@@ -1,5 +1,5 @@
 #!/bin/bash
-# wave life times of k_dfs on the headline targets (5 M-key table): speculation on / off.  tools/r4_life.sh <tag> [tests-k-expr]
+# wave life times of k_dfs on the headline targets (5 M-key table): speculation on / off.  tools/lifetimes_ab.sh <tag> [tests-k-expr]
 set -o pipefail
 tag=${1:-life}
 out=gpurun_out/$tag

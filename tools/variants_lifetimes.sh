@@ -1,5 +1,5 @@
 #!/bin/bash
-# wave life times of k_dfs for several builds of the library (km_amd/variants/*.so).  tools/r4_variants.sh <tag> [tests-k-expr]
+# wave life times of k_dfs for several builds of the library (km_amd/variants/*.so).  tools/variants_lifetimes.sh <tag> [tests-k-expr]
 set -o pipefail
 tag=${1:-var}
 out=gpurun_out/$tag
