@@ -135,6 +135,12 @@ __host__ __device__ inline uint64_t graph_ws_bytes(uint32_t ncap, uint32_t hcap,
 }
 
 
+// LDS of k_graph_pure per target: position table (16-bit, hcap slots), its losers' table (32-bit, hcap / 8 slots), the
+// packed target
+__host__ __device__ inline uint64_t pure_lds_bytes(uint32_t hcap, uint32_t words_cap) {
+  return (uint64_t)hcap * 2 + (uint64_t)(hcap / 8) * 4 + (uint64_t)words_cap * 8;
+}
+
 // ---------------------------------------------------------------------------- k_graph_pure
 // Unflagged targets (node list == the target's own k-mers, final right after k_seed):
 // decide whether the graph is the bare reference chain — all (k-1)-mer prefixes distinct
@@ -165,15 +171,17 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     return;
   }
   if (h_tflag) return;                         // k_graph handles it once k_dfs is done
-  const uint32_t hcap = a.hcap_pure;
-  if ((uint64_t)2 * (n_ref + 2) > (uint64_t)hcap || (a.dbg != 0 && !(a.dbg & 0x80u))) {
+  const uint32_t hcap = a.hcap_pure;                        // slots of the position table: a power of two >= 4 (n_ref + 1)
+  if ((uint64_t)4 * (n_ref + 2) > (uint64_t)hcap || n_ref >= 0xFFFFu || (a.dbg != 0 && !(a.dbg & 0x80u))) {
     if (tid == 0) { a.need_full[t] = 1; if (a.work_list) a.work_list[a.work_n[0] + atomicAdd(&a.work_n[1], 1u)] = t; }
     return;
   }
   const uint32_t* ncnt = a.node_cnt + nb;
   // the packed target: n_ref + k - 1 bases, (L + 31) / 32 + 1 words (the last one zero)
   const uint32_t nwords = (n_ref + (uint32_t)a.k - 1 + 31) >> 5;
-  uint64_t* words = reinterpret_cast<uint64_t*>(smem + (uint64_t)hcap * 4);
+  uint16_t* pos = reinterpret_cast<uint16_t*>(smem);                              // [hcap]
+  uint32_t* tab2 = reinterpret_cast<uint32_t*>(smem + (uint64_t)hcap * 2);        // [hcap / 8]: the losers of `pos`
+  uint64_t* words = reinterpret_cast<uint64_t*>(smem + pure_lds_bytes(hcap, 0));
   if (nwords + 1 > a.words_cap) {
     if (tid == 0) { a.need_full[t] = 1; if (a.work_list) a.work_list[a.work_n[0] + atomicAdd(&a.work_n[1], 1u)] = t; }
     return;
@@ -182,50 +190,50 @@ __global__ __launch_bounds__(64) void k_graph_pure(GraphArgs a) {
     const uint64_t* src = a.packed + h_woff;
     for (uint32_t w = tid; w <= nwords; w += NT) words[w] = src[w];
   }
-  // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of
-  // the last) distinct?  A set of 32-bit FINGERPRINTS at load <= 1/2 answers it: equal
-  // (k-1)-mers always meet (same fingerprint, same home); two different ones with the same
-  // fingerprint (2.6e-5 per target, whatever the load) only send the target to k_graph, which
-  // decides exactly.
-  uint32_t* fps = reinterpret_cast<uint32_t*>(smem);
+  // Are the n_ref + 1 (k-1)-mers of the target (the prefix of every k-mer and the suffix of the last) distinct?
+  // As k_dfs does for its node set (walk_kernel.h, "position table"): every (k-1)-mer stores its INDEX at the slot
+  // its low 32 bits hash to, with a plain store (the last one wins); whoever does not read its own index back lost
+  // the slot — to an equal (k-1)-mer (the answer is no) or to another one — and the losers (a tenth at load 1/4) go
+  // into a small exact table with compare-and-swap, where an equal one is met for sure: equal (k-1)-mers share
+  // both slots.  Round 3 entered all 471 as 32-bit fingerprints with compare-and-swap.
   {
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), zero = make_uint4(0u, 0u, 0u, 0u);
     uint4* q = reinterpret_cast<uint4*>(smem);
-    for (uint32_t x = tid; x < hcap / 4; x += NT) q[x] = zero;
+    for (uint32_t x = tid; x < hcap / 8; x += NT) q[x] = ones;                    // 2 hcap bytes
+    uint4* q2 = reinterpret_cast<uint4*>(tab2);
+    for (uint32_t x = tid; x < hcap / 32; x += NT) q2[x] = zero;                  // hcap / 2 bytes
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: LDS runs its operations in order
+  const uint32_t sh1 = 32u - (uint32_t)__ffs((int)hcap) + 1u, m2 = hcap / 8 - 1;
+  auto part_of = [&](uint32_t j) -> uint64_t {           // (k-1)-mer j: prefix of k-mer j, suffix of the last one for j = n_ref
+    return j < n_ref ? (kmer_from_words(words, j, a.k) >> 2) : (kmer_from_words(words, n_ref - 1, a.k) & a.pmask);
+  };
+  auto h1 = [&](uint64_t key) -> uint32_t { return ((uint32_t)key * 0x9E3779B1u) >> sh1; };
   uint32_t not_pure = 0;
   uint32_t mincov = 0xFFFFFFFFu, maxcov = 0;
-  auto insert = [&](uint64_t key) {
-    uint32_t fp = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
-    fp ^= fp >> 16;
-    fp = fp ? fp : 1u;
-    uint32_t s = __umulhi(fp * 0xC2B2AE35u, hcap);
-    for (uint32_t step = 0; step < hcap; ++step) {
-      const uint32_t old = atomicCAS(&fps[s], 0u, fp);
-      if (old == 0u) return;
-      if (old == fp) { not_pure = 1; return; }
-      if (++s == hcap) s = 0;
-    }
-    not_pure = 1;
-  };
-  // four independent loads in flight per lane, then the (LDS-atomic) inserts
-  for (uint32_t j0 = tid; j0 <= n_ref; j0 += 4 * NT) {
-    uint64_t kk[4];
-    uint32_t cc[4];
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      const uint32_t j = j0 + u * NT;
-      kk[u] = j < n_ref ? (kmer_from_words(words, j, a.k) >> 2)
-                        : (j == n_ref ? (kmer_from_words(words, n_ref - 1, a.k) & a.pmask) : 0);
-      cc[u] = j < n_ref ? ncnt[j] : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      if (j0 + u * NT > n_ref) break;
-      insert(kk[u]);
-      mincov = cc[u] < mincov ? cc[u] : mincov;
-      if (j0 + u * NT < n_ref) maxcov = cc[u] > maxcov ? cc[u] : maxcov;
+  for (uint32_t j = tid; j <= n_ref; j += NT) pos[h1(part_of(j))] = (uint16_t)j;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (uint32_t j0 = 0; j0 <= n_ref; j0 += NT) {         // wave-uniform trip count
+    const uint32_t j = j0 + tid;
+    if (j <= n_ref) {
+      const uint32_t cc = j < n_ref ? ncnt[j] : 0xFFFFFFFFu;
+      const uint64_t key = part_of(j);
+      const uint32_t w = pos[h1(key)];
+      if (w != j) {
+        if (part_of(w) == key) not_pure = 1;             // (w is an index some (k-1)-mer stored)
+        else {
+          uint32_t s2 = (((uint32_t)key * 0x85EBCA6Bu) ^ ((uint32_t)(key >> 32) * 0xC2B2AE35u)) >> 7 & m2;
+          for (uint32_t step = 0; step <= m2; ++step) {
+            const uint32_t old = atomicCAS(&tab2[s2], 0u, j + 1);
+            if (old == 0u) break;
+            if (part_of(old - 1) == key) { not_pure = 1; break; }
+            s2 = (s2 + 1) & m2;
+            if (step == m2) not_pure = 1;                // full (cannot happen at this load): k_graph decides
+          }
+        }
+      }
+      mincov = cc < mincov ? cc : mincov;
+      if (j < n_ref) maxcov = cc > maxcov ? cc : maxcov;
     }
   }
   if (__any((int)not_pure)) {

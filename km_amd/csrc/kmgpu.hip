@@ -1393,7 +1393,7 @@ static bool fast_fits(const km_batch* b, uint32_t nref, uint32_t bcap) {
   const uint32_t ncap = nref + FAST_EXTRA + 2, hcap = round_up(ncap + ncap / 2 + 1, 64);
   return walk_lds_bytes(hs, wc, bcap, walk_pcap(nref), 2) <= FAST_LDS_LIMIT &&
          graph_ws_bytes<uint16_t>(ncap, hcap, wc) <= FAST_LDS_LIMIT && ncap < 0xFFFF &&
-         (uint64_t)hcap * 4 + (uint64_t)wc * 8 <= FAST_LDS_LIMIT;
+         (uint64_t)hcap * 4 + (uint64_t)wc * 8 <= FAST_LDS_LIMIT;   // (k_graph_pure hands over what its own table cannot hold)
 }
 
 static void fast_geometry(km_batch* b) {
@@ -1425,13 +1425,12 @@ static void fast_geometry(km_batch* b) {
   ga.hcap = round_up(ga.ncap + ga.ncap / 2 + 1, 64);
   ga.words_cap = wa.words_cap;
   b->graph_lds = (uint32_t)graph_ws_bytes<uint16_t>(ga.ncap, ga.hcap, ga.words_cap);
-  ga.hcap_pure = round_up(2 * (nref + 2), 64);                   // 32-bit fingerprints at load <= 1/2 (pipelined step
-                                                                 // vs load 1/4: -2.5 %; load 3/4: +3 % — resident
-                                                                 // waves against probe chains)
-  b->pure_lds = ga.hcap_pure * 4 + ga.words_cap * 8;
+  ga.hcap_pure = 64;                                             // position table at load <= 1/4 (graph_kernel.h: k_graph_pure)
+  while (ga.hcap_pure < 4 * (nref + 2)) ga.hcap_pure <<= 1;
+  b->pure_lds = (uint32_t)pure_lds_bytes(ga.hcap_pure, ga.words_cap);
   if (b->pure_lds > FAST_LDS_LIMIT) {                            // all -> need_full
     ga.hcap_pure = 64;
-    b->pure_lds = 256 + ga.words_cap * 8;
+    b->pure_lds = (uint32_t)pure_lds_bytes(64, ga.words_cap);
   }
   // the epilogue of k_dfs answers the regular flagged targets when the graph stage is wanted in full
   // (KM_EPILOGUE=0: diagnostics, everything through k_graph as in round 2)
