@@ -813,6 +813,7 @@ struct Knobs {
   long spin_us = 0;             // KM_SPIN_US: poll the delivery event this long before sleeping on it
   uint32_t graph_grid = 0;      // KM_GRAPH_GRID: blocks of k_graph when the epilogue of k_dfs is on (tests: force the overflow path)
   bool speculate = true;        // KM_SPECULATE=0: k_dfs walks every chain one lookup after the other (results unchanged)
+  bool dfs_grid_full = false;   // KM_DFS_GRID_FULL=1: one block of k_dfs per target of the batch, as before round 4
 };
 Knobs read_knobs() {
   Knobs q;
@@ -829,6 +830,7 @@ Knobs read_knobs() {
   q.spin_us = num("KM_SPIN_US", 0);
   q.graph_grid = (uint32_t)std::max<long>(0, num("KM_GRAPH_GRID", 0));
   q.speculate = num("KM_SPECULATE", 1) != 0;
+  q.dfs_grid_full = num("KM_DFS_GRID_FULL", 0) != 0;
   return q;
 }
 const Knobs& knobs() {
@@ -991,6 +993,7 @@ struct km_batch {
   // that read two words each, 8.6 us alone and 31 us inside the pipeline.  More entries than blocks go to the
   // large tier (graph_kernel.h), and the next run's grid is larger.
   uint32_t graph_list_seen = 0xFFFFFFFFu;   // (nothing seen yet: the default grid)
+  uint32_t flagged_seen = 0xFFFFFFFFu;      // flagged targets of the last delivered run: the grid of k_dfs
   // host mirrors after sync
   std::vector<uint32_t> h_status, h_gstatus, h_n_nodes, h_n_ref, h_npaths, h_pathbase;
   unsigned long long h_overflow = 0;
@@ -1685,9 +1688,16 @@ extern "C" int km_batch_run(km_batch_t* b, int stages, void* stream) {
     // k_graph_pure beside k_dfs on a side stream per batch; KM_RUN_SERIAL selected today's order.)
     ga.use_need_full = 1;
     (void)serial;
+    // one single-wave block per FLAGGED target: the grid follows what the batch's last delivery reported (x 1.25 + 64;
+    // the whole batch until one has been seen) — 6 000 of the headline batch's 10 000 blocks used to leave after one
+    // load, each having claimed its LDS first.  More flagged targets than blocks: the kernel hands the rest to the
+    // large tier (walk_kernel.h), and the next run's grid is larger.
+    uint32_t dfs_grid = b->n_targets;
+    if (b->flagged_seen != 0xFFFFFFFFu && !knobs().dfs_grid_full)
+      dfs_grid = (uint32_t)std::min<uint64_t>(dfs_grid, (uint64_t)b->flagged_seen + b->flagged_seen / 4 + 64);
     auto launch_dfs = [&]() {
-      if (wa.tab.k == 31) hipLaunchKernelGGL((k_dfs<false, 31>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
-      else hipLaunchKernelGGL((k_dfs<false, 0>), dim3(b->n_targets), dim3(64), b->walk_lds, st, wa);
+      if (wa.tab.k == 31) hipLaunchKernelGGL((k_dfs<false, 31>), dim3(dfs_grid), dim3(64), b->walk_lds, st, wa);
+      else hipLaunchKernelGGL((k_dfs<false, 0>), dim3(dfs_grid), dim3(64), b->walk_lds, st, wa);
     };
     // diagnostics (KM_DFS_REPLAY=1|2): k_dfs twice, the SECOND launch is the one timed — its instruction
     // cache is warm; with 2 a 1 GiB memset in between flushes L2 / Infinity Cache (data cold again)
@@ -2079,6 +2089,11 @@ static int finish_result(km_batch* b, bool need_full) {
     }
     if (T[OT_SERIAL] != b->serial) return fail(KM_E_HIP, "delivery buffer out of step");
     const unsigned long long nh = T[OT_NEEDS_HOST];
+    {
+      const uint32_t fl = (uint32_t)std::min<unsigned long long>(T[OT_N_FLAGGED], 0x7FFFFFFFull);
+      if (b->gexec && b->flagged_seen != 0xFFFFFFFFu && (fl > b->flagged_seen + b->flagged_seen / 8 + 32 || 4 * fl + 256 < b->flagged_seen)) drop_graph(b);
+      b->flagged_seen = fl;
+    }
     if (b->ran_graph && b->graph_mode == 0) {
       const uint32_t seen = (uint32_t)std::min<unsigned long long>(T[OT_N_GRAPH_LIST], 0x7FFFFFFFull);
       // (a captured step holds its grid: it is dropped when the list outgrows a quarter of it or shrinks to a 16th)

@@ -639,6 +639,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KM_DFS_WAVES
   } else {
     const uint4 r0 = a.flag_rec[2 * blockIdx.x], r1 = a.flag_rec[2 * blockIdx.x + 1];
     const uint32_t n_list = *a.n_list_dev;
+    // The grid follows the number of flagged targets the batch's last delivery reported (kmgpu.hip: launch_dfs), not
+    // the batch size.  Should more be flagged than there are blocks, block 0 hands the rest to the large tier, as
+    // any target is that this tier cannot hold (the next run's grid is larger).
+    if (blockIdx.x == 0 && n_list > gridDim.x) {
+      for (uint32_t e = gridDim.x + lane; e < n_list; e += 64) {
+        const uint32_t te = a.flag_rec[2 * e].x;
+        a.status[te] = T_NEEDS_BIG;
+        if (a.epi != nullptr) { a.epi->t_refmax[te] = NOT_BARE; a.epi->left[atomicAdd(a.epi->n_left, 1u)] = te; }
+        if (a.big_ctl) { const uint32_t at = atomicAdd(&a.big_ctl[0], 1u); if (at < a.big_slots) a.big_walk[at] = te; }
+      }
+    }
     if (blockIdx.x >= n_list) return;
     t = r0.x; n_ref = r0.y; nb = ((uint64_t)r0.w << 32) | r0.z;
     fwo = r1.x; wo = r1.y;

@@ -1713,3 +1713,49 @@ def test_graph_log_matches_the_oracle_and_the_reference():
         seen_loops += len(got)
     assert seen_loops >= 3 and n_loops == sum(len(v) for v in loops.values())
     db.close()
+
+
+def test_dfs_grid_follows_the_flagged_count_and_overflows_into_the_large_tier():
+    """The grid of k_dfs is sized from the number of flagged targets the batch's LAST delivery reported; a batch whose
+    next target set has far more of them than that overflows the grid, and the kernel hands the rest to the large
+    tier.  Same arrays as a workspace that has never seen another set, and the oracle's on a sample."""
+    from oracle import c_oracle
+    few = synth.make_case(n_targets=500, length=300, k=31, n_keys=80_000, seed=61, variant_frac=0.04, exact_pad=False)
+    many = synth.make_case(n_targets=500, length=300, k=31, n_keys=80_000, seed=62, variant_frac=0.9,
+                           variants_per_target=(1, 2), exact_pad=False)
+    keys = np.concatenate([few["keys"], many["keys"]])
+    counts = np.concatenate([few["counts"], many["counts"]])
+    keys, first = np.unique(keys, return_index=True)
+    counts = counts[first]
+    db = kmlib.Database.from_records(keys, counts, 31).upload(0)
+    seq_few = [km.decode(r) for r in few["targets"]]
+    seq_many = [km.decode(r) for r in many["targets"]]
+    fresh = kmlib.Batch(db, max_targets=500, max_total_bases=500 * 300)
+    fresh.set_targets(seq_many)
+    fresh.run()
+    want = fresh.fetch()
+    b = kmlib.Batch(db, max_targets=500, max_total_bases=500 * 300)
+    b.set_targets(seq_few)
+    b.run()
+    r0 = b.fetch()
+    assert 5 <= b.debug_counts()[0] <= 60
+    b.set_targets(seq_many)
+    b.run()                                                      # a grid of ~100 blocks for ~450 flagged targets
+    got = b.fetch()
+    assert b.debug_counts()[0] > 400 and int(got["n_big_tier"]) > 250
+    for name in _R4_FIELDS:
+        assert np.array_equal(got[name], want[name]), name
+    b.run()                                                      # ... and the next run's grid holds them all
+    again = b.fetch()
+    assert int(again["n_big_tier"]) == int(want["n_big_tier"])
+    for name in _R4_FIELDS:
+        assert np.array_equal(again[name], want[name]), name
+    co = c_oracle.COracle(keys, counts, 31)
+    noff, poff = got["node_off"].astype(np.int64), got["path_off"].astype(np.int64)
+    for t in range(0, 500, 7):
+        w = co.analyse(many["targets"][t])
+        assert (got["node_kmer"][noff[t]:noff[t + 1]] == w["kmers"]).all() and int(got["probes"][t]) == w["probes"], t
+        assert [kmlib.expand_path(got, p).tolist() for p in range(poff[t], poff[t + 1])] == w["paths"], t
+    b.close()
+    fresh.close()
+    db.close()
