@@ -54,6 +54,8 @@ struct Target {
   const Path* paths;        // n_paths of them, in the worker's scratch
   size_t n_paths;
   const uint32_t* min_cov;
+  const uint8_t* is_ref;    // per path: it is 0, 1, .. n_ref-1 (read off the path's runs when it was laid out)
+  bool plain;               // seq is upper-case ACGT throughout: its k-mers spell as they stand
 };
 
 struct Split { int64_t start, end_ref, end_var, end_ovl; };
@@ -129,58 +131,6 @@ inline void slice(const Path& a, int64_t lo, int64_t hi, Path* out) {
   if (hi > lo) out->assign(a.begin() + lo, a.begin() + hi);
 }
 
-std::string unpack(uint64_t kmer, int k) {
-  std::string s((size_t)k, 'A');
-  for (int i = k - 1; i >= 0; --i) { s[(size_t)i] = LAST[kmer & 3]; kmer >>= 2; }
-  return s;
-}
-
-std::string spell(const Target& t, const Path& p, bool whole_first) {
-  if (p.empty()) return std::string();
-  std::string s = whole_first ? unpack(kmer_of(t, p[0]), t.k) : std::string(1, tail_of(t, p[0]));
-  s.reserve(s.size() + p.size());
-  for (size_t i = 1; i < p.size(); ++i) s.push_back(tail_of(t, p[i]));
-  return s;
-}
-
-inline std::string suffix(const std::string& s, size_t n) { return n >= s.size() ? s : s.substr(s.size() - n); }
-
-// 0 ok, 1 IndexError, 2 "mutation identification could be incorrect", 3 assertion
-int name_variant(const Target& t, const Path& ref, const Path& alt, int64_t offset, std::string* out) {
-  Split sp;
-  if (!split_paths(ref, alt, t.k, &sp)) return 1;
-  Path only_ref, only_var;
-  slice(ref, sp.start, sp.end_ref, &only_ref);
-  slice(alt, sp.start, sp.end_var, &only_var);
-  if ((int64_t)ref.size() - (int64_t)only_ref.size() + (int64_t)only_var.size() != (int64_t)alt.size()) return 2;
-  std::string gone = spell(t, only_ref, false), neu = spell(t, only_var, false);
-  if (!gone.empty()) {
-    if (gone == neu) return 3;
-    // while gone[-(cut+1):] == neu[-(cut+1):]: cut += 1 — with gone != neu that is the length of the common suffix
-    // (once cut + 1 exceeds the shorter string the two slices differ in length)
-    size_t cut = 0;
-    const size_t lim = std::min(gone.size(), neu.size());
-    while (cut < lim && gone[gone.size() - 1 - cut] == neu[neu.size() - 1 - cut]) ++cut;
-    if (cut) {
-      gone = cut >= gone.size() ? std::string() : gone.substr(0, gone.size() - cut);
-      neu = cut >= neu.size() ? std::string() : neu.substr(0, neu.size() - cut);
-    }
-  }
-  const char* kind;
-  if (sp.end_ref == sp.end_var) kind = sp.start == sp.end_ref ? "Reference" : "Substitution";
-  else if (sp.start == sp.end_ovl) kind = "ITD";
-  else if (sp.end_ref < sp.end_var) kind = gone.empty() ? "Insertion" : "Indel";
-  else kind = neu.empty() ? "Deletion" : "Indel";
-  if (!strcmp(kind, "Reference")) { *out = "Reference\t"; return 0; }
-  for (char& c : gone) c = (char)tolower((unsigned char)c);
-  char buf[64];
-  snprintf(buf, sizeof buf, "%lld:", (long long)(sp.start + t.k + offset));
-  *out = std::string(kind) + "\t" + buf + gone + "/" + neu;
-  snprintf(buf, sizeof buf, ":%lld", (long long)(sp.end_ref + 1 + offset));
-  *out += buf;
-  return 0;
-}
-
 // Thin SVD of the n x m matrix held column by column in u (m small) by one-sided Jacobi
 // rotations (Hestenes): on return the columns of u are sigma_j * u_j, v holds the right
 // singular vectors in its columns and sig the singular values.  Works on A itself — forming
@@ -195,20 +145,26 @@ void jacobi_svd(std::vector<std::vector<double>>& u, int m, std::vector<double>&
     for (int p = 0; p < m; ++p)
       for (int q = p + 1; q < m; ++q) {
         double alpha = 0, beta = 0, gamma = 0;
+        double* const cp = u[(size_t)p].data();
+        double* const cq = u[(size_t)q].data();
         for (size_t i = 0; i < n; ++i) {
-          alpha += u[(size_t)p][i] * u[(size_t)p][i];
-          beta += u[(size_t)q][i] * u[(size_t)q][i];
-          gamma += u[(size_t)p][i] * u[(size_t)q][i];
+          alpha += cp[i] * cp[i];
+          beta += cq[i] * cq[i];
+          gamma += cp[i] * cq[i];
         }
         if (gamma == 0.0 || std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+        // one of the two is a null column already (norm below 1e-14 of the other's: under the cut-off on the
+        // singular values, so it is dropped below whatever it points at): rotating it against the other only
+        // stirs rounding noise, sweep after sweep, and an exactly rank-deficient fit never came to rest
+        if (std::min(alpha, beta) <= 1e-28 * std::max(alpha, beta)) continue;
         rotated = true;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
         const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
         for (size_t i = 0; i < n; ++i) {
-          const double up = u[(size_t)p][i], uq = u[(size_t)q][i];
-          u[(size_t)p][i] = c * up - sn * uq;
-          u[(size_t)q][i] = sn * up + c * uq;
+          const double up = cp[i], uq = cq[i];
+          cp[i] = c * up - sn * uq;
+          cq[i] = sn * up + c * uq;
         }
         for (int r = 0; r < m; ++r) {
           const double vp = v[(size_t)r * m + p], vq = v[(size_t)r * m + q];
@@ -236,14 +192,22 @@ struct RowRec {
   std::string note;           // "vs_ref" / "cluster N n=M"
 };
 
+struct Group { int64_t lo, hi; std::vector<int> members; };
+
 struct Scratch {
   std::vector<Path> paths;
+  std::vector<std::vector<int64_t>> path_runs;   // per path: its stretches of consecutive nodes as (first, last + 1) pairs
+  std::vector<int64_t> ref_run, cref_run;        // the same for `ref` and `cref` (one stretch each)
+  std::vector<const std::vector<int64_t>*> set_runs;   // for the paths of `set`: their stretches when known, else NULL
   std::vector<uint32_t> min_cov;
+  std::vector<uint8_t> is_ref;         // per path of the target
   std::vector<uint32_t> counts32;      // a target's counts when the view carries them as 16-bit values
   std::vector<uint64_t> prefix;        // prefix[i] = sum of the float32 values of the counts of nodes < i
   Path ref, cref;
   struct Event { int64_t pos; int32_t c, d; };
   std::vector<Event> events;
+  std::vector<int64_t> seg;            // the stretches of nodes that lie on at least one path of the fit (lo, hi pairs)
+  std::vector<int32_t> cmap;
   std::vector<int32_t> row;
   std::vector<Path> clipped;
   std::vector<const Path*> set;
@@ -252,64 +216,116 @@ struct Scratch {
   std::vector<RowRec> rows;
   size_t n_rows = 0;
   std::vector<size_t> order;
-  std::string tmp;
+  std::string tmp, gone, neu, name, cref_seq;
+  std::vector<int> todo;
+  std::vector<Group> groups;
+  size_t n_groups = 0;
   std::vector<Split> diffs;
 };
 
 // km_amd/report.py: fit_paths over the node counts as float32 values (w.prefix holds their running sums) followed
 // by -1, -1 (the two capping nodes, on no path).  Leaves coef and rvaf in the scratch (rvaf == coef when every
 // coefficient is 0).
-void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_total, const uint32_t* raw_counts) {
-  const int m = (int)paths.size();
-  const size_t M = (size_t)m;
-  // contrib[i][c] = occurrences of node i on path c.  The rows of that matrix take few distinct values (a node
-  // lies on the reference only, on a variant path only, on both, ...): everything below works on those PATTERNS —
-  // pattern q with its row, the number of nodes N_q that have it and the sum S_q of their counts — instead of on
-  // the ~500 nodes, and the patterns are read off the RUNS of the paths (a path is a few stretches of consecutive
-  // node indices): between two neighbouring run ends the row is constant.  Patterns are numbered in the order of
-  // their first node, as a scan over the nodes would find them; the all-zero row (nodes on none of the paths,
-  // the two capping nodes) adds exact zeros to every sum below and is left out.  S_q comes from running sums of
-  // the counts — integers, so exact in any order.
-  std::vector<int32_t>& pat = w.pat;                    // n_pat rows of m
-  std::vector<double>&pat_sum = w.pat_sum, &pat_n = w.pat_n;
-  pat.clear(); pat_sum.clear(); pat_n.clear();
-  size_t n_pat = 0;
-  {
-    std::vector<Scratch::Event>& ev = w.events;
-    ev.clear();
-    for (int c = 0; c < m; ++c) {
-      const Path& p = *paths[(size_t)c];
-      const size_t n = p.size();
-      size_t i = 0;
-      while (i < n) {
-        size_t j = i + 1;
-        while (j < n && p[j] == p[j - 1] + 1) ++j;
-        ev.push_back(Scratch::Event{p[i], c, 1});
-        ev.push_back(Scratch::Event{p[j - 1] + 1, c, -1});
-        i = j;
+//
+// contrib[i][c] = occurrences of node i on path c.  The rows of that matrix take few distinct values (a node
+// lies on the reference only, on a variant path only, on both, ...): everything works on those PATTERNS —
+// pattern q with its row, the number of nodes N_q that have it and the sum S_q of their counts — instead of on
+// the ~500 nodes, and the patterns are read off the RUNS of the paths (a path is a few stretches of consecutive
+// node indices): between two neighbouring run ends the row is constant.  Patterns are numbered in the order of
+// their first node, as a scan over the nodes would find them; the all-zero row (nodes on none of the paths,
+// the two capping nodes) adds exact zeros to every sum below and is left out.  S_q comes from running sums of
+// the counts — integers, so exact in any order.  Returns the number of patterns (w.pat, w.pat_sum, w.pat_n).
+size_t fit_patterns(Scratch& w, const std::vector<const Path*>& paths) {
+  const size_t M = paths.size();
+  std::vector<Scratch::Event>& ev = w.events;
+  ev.clear();
+  const bool have_runs = w.set_runs.size() == M;
+  for (size_t c = 0; c < M; ++c) {
+    if (have_runs && w.set_runs[c]) {                   // the stretches are known: no scan of the path
+      const std::vector<int64_t>& rr = *w.set_runs[c];
+      for (size_t i = 0; i + 1 < rr.size(); i += 2) {
+        if (rr[i + 1] <= rr[i]) continue;
+        ev.push_back(Scratch::Event{rr[i], (int32_t)c, 1});
+        ev.push_back(Scratch::Event{rr[i + 1], (int32_t)c, -1});
       }
+      continue;
     }
-    std::sort(ev.begin(), ev.end(), [](const Scratch::Event& x, const Scratch::Event& y) { return x.pos < y.pos; });
-    std::vector<int32_t>& row = w.row;
-    row.assign(M, 0);
-    int64_t active = 0, prev = 0;
-    size_t last = 0;                                    // neighbours mostly share their pattern
-    for (size_t e = 0; e < ev.size();) {
-      const int64_t pos = ev[e].pos;
-      if (active && pos > prev) {                       // nodes prev .. pos-1 have the row `row`
-        auto same = [&](size_t q) { return memcmp(pat.data() + q * M, row.data(), M * sizeof(int32_t)) == 0; };
-        size_t q = last;
-        if (!(q < n_pat && same(q)))
-          for (q = 0; q < n_pat; ++q) if (same(q)) break;
-        if (q == n_pat) { pat.insert(pat.end(), row.begin(), row.end()); pat_sum.push_back(0.0); pat_n.push_back(0.0); ++n_pat; }
-        pat_sum[q] += (double)(w.prefix[(size_t)pos] - w.prefix[(size_t)prev]);
-        pat_n[q] += (double)(pos - prev);
-        last = q;
-      }
-      for (; e < ev.size() && ev[e].pos == pos; ++e) { row[(size_t)ev[e].c] += ev[e].d; active += ev[e].d; }
-      prev = pos;
+    const Path& p = *paths[c];
+    const size_t n = p.size();
+    const int64_t* pd = p.data();
+    size_t i = 0;
+    while (i < n) {
+      size_t j = i + 1;
+      while (j < n && pd[j] == pd[j - 1] + 1) ++j;
+      ev.push_back(Scratch::Event{pd[i], (int32_t)c, 1});
+      ev.push_back(Scratch::Event{pd[j - 1] + 1, (int32_t)c, -1});
+      i = j;
     }
   }
+  const size_t n_ev = ev.size();
+  Scratch::Event* e = ev.data();
+  for (size_t i = 1; i < n_ev; ++i) {                   // a handful of events: insertion sort by position (the order
+    const Scratch::Event x = e[i];                      // of equal positions does not matter: they are applied together)
+    size_t j = i;
+    for (; j > 0 && e[j - 1].pos > x.pos; --j) e[j] = e[j - 1];
+    e[j] = x;
+  }
+  // at most one pattern per gap between events
+  w.pat.resize((n_ev + 1) * M);
+  w.pat_sum.resize(n_ev + 1);
+  w.pat_n.resize(n_ev + 1);
+  w.row.assign(M, 0);
+  int32_t* pat = w.pat.data();
+  int32_t* row = w.row.data();
+  double *pat_sum = w.pat_sum.data(), *pat_n = w.pat_n.data();
+  const uint64_t* prefix = w.prefix.data();
+  size_t n_pat = 0;
+  int64_t active = 0, prev = 0;
+  size_t last = 0;                                      // neighbours mostly share their pattern
+  w.seg.clear();
+  for (size_t x = 0; x < n_ev;) {
+    const int64_t pos = e[x].pos;
+    if (active && pos > prev) {                         // nodes prev .. pos-1 have the row `row`
+      w.seg.push_back(prev); w.seg.push_back(pos);
+      auto same = [&](size_t q) {
+        for (size_t c = 0; c < M; ++c) if (pat[q * M + c] != row[c]) return false;
+        return true;
+      };
+      size_t q = last;
+      if (!(q < n_pat && same(q)))
+        for (q = 0; q < n_pat; ++q) if (same(q)) break;
+      if (q == n_pat) {
+        for (size_t c = 0; c < M; ++c) pat[q * M + c] = row[c];
+        pat_sum[q] = 0.0; pat_n[q] = 0.0;
+        ++n_pat;
+      }
+      pat_sum[q] += (double)(prefix[(size_t)pos] - prefix[(size_t)prev]);
+      pat_n[q] += (double)(pos - prev);
+      last = q;
+    }
+    for (; x < n_ev && e[x].pos == pos; ++x) { row[(size_t)e[x].c] += e[x].d; active += e[x].d; }
+    prev = pos;
+  }
+  return n_pat;
+}
+
+// The numbers of the fit from the patterns.  FM = the number of paths when it is 2, 3 or 4 (the loops over paths
+// then unroll over arrays on the stack; the operations and their order are those of the general form, FM = 0,
+// so the results are the same bit for bit).
+template <int FM>
+void fit_solve(Scratch& w, const std::vector<const Path*>& paths, const size_t n_pat, int64_t n_total,
+               const uint32_t* raw_counts) {
+  const size_t M = FM ? (size_t)FM : paths.size();
+  const int m = (int)M;
+  constexpr size_t CAP = FM ? (size_t)FM : 1;
+  double g_s[CAP * CAP], atb_s[CAP], ev_s[CAP * CAP], coef_s[CAP], grad_s[CAP];
+  double *g = g_s, *atb = atb_s, *ev = ev_s, *coef = coef_s, *grad = grad_s;
+  if (!FM) {
+    w.g.resize(M * M); w.atb.resize(M); w.ev.resize(M * M); w.coef.resize(M); w.grad.resize(M);
+    g = w.g.data(); atb = w.atb.data(); ev = w.ev.data(); coef = w.coef.data(); grad = w.grad.data();
+  }
+  const int32_t* pat = w.pat.data();
+  const double *pat_sum = w.pat_sum.data(), *pat_n = w.pat_n.data();
   // Minimum-norm least squares with numpy's rcond=None cut-off (eps * max(n, m) * sigma_max on the singular
   // values).  A^T A = sum_q N_q pat_q pat_q^T and A^T b = sum_q S_q pat_q are sums of small integers times
   // counts, the singular values of A the square roots of the eigenvalues of the m x m matrix A^T A, its
@@ -317,20 +333,18 @@ void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_tota
   // Squaring the condition number is harmless while the paths are well separated; a fit with a small or
   // vanishing singular value (near-identical or identical paths: a rank-deficient cluster) goes through
   // the one-sided Jacobi SVD of A itself, as every fit did before.
-  std::vector<double>& coef = w.coef;
-  coef.assign(M, 0.0);
+  for (size_t i = 0; i < M; ++i) coef[i] = 0.0;
   bool solved = false;
   {
-    std::vector<double>&g = w.g, &atb = w.atb, &ev = w.ev;
-    g.assign(M * M, 0.0);
-    atb.assign(M, 0.0);
+    for (size_t i = 0; i < M * M; ++i) g[i] = 0.0;
+    for (size_t i = 0; i < M; ++i) atb[i] = 0.0;
     for (size_t q = 0; q < n_pat; ++q)
       for (size_t r = 0; r < M; ++r) {
         atb[r] += (double)pat[q * M + r] * pat_sum[q];
         for (size_t c = 0; c < M; ++c) g[r * M + c] += pat_n[q] * (double)pat[q * M + r] * (double)pat[q * M + c];
       }
     // cyclic Jacobi on the symmetric g: g -> diag(lambda), ev columns = eigenvectors
-    ev.assign(M * M, 0.0);
+    for (size_t i = 0; i < M * M; ++i) ev[i] = 0.0;
     for (size_t i = 0; i < M; ++i) ev[i * M + i] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
       double off = 0.0, diag = 0.0;
@@ -373,12 +387,18 @@ void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_tota
     }
   }
   if (!solved) {
-    std::vector<std::vector<double>> u(M, std::vector<double>((size_t)n_total, 0.0));
+    // only over the nodes that lie on a path, in their order: the rows of every other node (the two capping nodes
+    // among them) are zero and stay zero under the rotations — exact zeros in every sum below
+    w.cmap.resize((size_t)n_total);
+    size_t n_on = 0;
+    for (size_t sgi = 0; sgi + 1 < w.seg.size(); sgi += 2)
+      for (int64_t i = w.seg[sgi]; i < w.seg[sgi + 1]; ++i) w.cmap[(size_t)i] = (int32_t)n_on++;
+    std::vector<std::vector<double>> u(M, std::vector<double>(n_on, 0.0));
     for (size_t c = 0; c < M; ++c)
-      for (int64_t node : *paths[c]) u[c][(size_t)node] += 1.0;
-    std::vector<float> counts((size_t)n_total);
-    for (int64_t i = 0; i + 2 < n_total; ++i) counts[(size_t)i] = (float)raw_counts[i];
-    counts[(size_t)n_total - 2] = counts[(size_t)n_total - 1] = -1.0f;
+      for (int64_t node : *paths[c]) u[c][(size_t)w.cmap[(size_t)node]] += 1.0;
+    std::vector<float> counts(n_on);
+    for (size_t sgi = 0; sgi + 1 < w.seg.size(); sgi += 2)
+      for (int64_t i = w.seg[sgi]; i < w.seg[sgi + 1]; ++i) counts[(size_t)w.cmap[(size_t)i]] = (float)raw_counts[i];
     std::vector<double> v, sig;
     jacobi_svd(u, m, v, sig);
     double smax = 0.0;
@@ -391,21 +411,22 @@ void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_tota
       if (smax > 0 && sj > 1e-14 * smax && sj < 1e-6 * smax) g_tie = true;
       if (!(sj > cutoff)) continue;
       double proj = 0.0;                              // (sigma_j u_j) . b / sigma_j^2
-      for (int64_t i = 0; i < n_total; ++i) proj += u[j][(size_t)i] * (double)counts[(size_t)i];
+      for (size_t i = 0; i < n_on; ++i) proj += u[j][i] * (double)counts[i];
       proj /= sj * sj;
       for (size_t r = 0; r < M; ++r) coef[r] += v[r * M + j] * proj;
     }
   }
-  for (double& c : coef) if (c < 0) c = 0;
+  for (size_t c = 0; c < M; ++c) if (coef[c] < 0) coef[c] = 0;
   // Projected gradient refinement (km/utils/PathQuant.py:111-142): grad_c = 2/n * sum_i (count_i - est_i) * contrib_ic
   // with est_i = sum_c contrib_ic * coef_c, step 0.1, until max |grad| <= 0.01, evaluated per pattern:
   // grad_c = 2/n * sum_q pat_qc * (S_q - N_q * est_q).  The same numbers in exact arithmetic; in floating point
   // the sums are grouped differently, which matters as little as the difference between two BLAS builds does
   // to the reference itself (printed values near a rounding tie are flagged and recomputed with numpy: err 100).
-  std::vector<double>&grad = w.grad, &resid = w.resid;
-  grad.assign(M, 0.0);
-  resid.assign(n_pat, 0.0);
+  for (size_t c = 0; c < M; ++c) grad[c] = 0.0;
+  w.resid.resize(n_pat);
+  double* resid = w.resid.data();
   double step = std::numeric_limits<double>::infinity();
+  long iters = 0;
   while (step > 0.01) {
     for (size_t q = 0; q < n_pat; ++q) {
       double e = 0.0;
@@ -425,15 +446,27 @@ void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_tota
       if (grad[c] != grad[c]) nan = true;
       step = std::max(step, std::fabs(grad[c]));
     }
-    ++g_fit_iters;
+    ++iters;
     if (nan) break;                                 // np.max of a NaN is NaN; NaN > 0.01 is False
   }
+  g_fit_iters += iters;
   double mx = -std::numeric_limits<double>::infinity(), sum = 0.0;
-  for (double c : coef) { mx = std::max(mx, c); sum += c; }
+  for (size_t c = 0; c < M; ++c) { mx = std::max(mx, coef[c]); sum += coef[c]; }
+  if (FM) w.coef.assign(coef, coef + M);
   w.rvaf.resize(M);
-  if (mx == 0) w.rvaf = coef;
+  if (mx == 0) w.rvaf = w.coef;
   else
-    for (size_t i = 0; i < M; ++i) w.rvaf[i] = coef[i] / sum;
+    for (size_t i = 0; i < M; ++i) w.rvaf[i] = w.coef[i] / sum;
+}
+
+void fit_paths(Scratch& w, const std::vector<const Path*>& paths, int64_t n_total, const uint32_t* raw_counts) {
+  const size_t n_pat = fit_patterns(w, paths);
+  switch (paths.size()) {
+    case 2: fit_solve<2>(w, paths, n_pat, n_total, raw_counts); break;
+    case 3: fit_solve<3>(w, paths, n_pat, n_total, raw_counts); break;
+    case 4: fit_solve<4>(w, paths, n_pat, n_total, raw_counts); break;
+    default: fit_solve<0>(w, paths, n_pat, n_total, raw_counts); break;
+  }
 }
 
 // Exact least-squares answers are ratios with small denominators (means of integer counts), so
@@ -504,7 +537,7 @@ inline void put_int(std::string& out, long long v) {
   out.append(p, (size_t)(e - p));
 }
 
-// the sequence a path spells, appended to `out` (spell() without the temporary)
+// the sequence a path spells, appended to `out`
 void put_spell(std::string& out, const Target& t, const Path& p, bool whole_first) {
   if (p.empty()) return;
   const size_t at = out.size();
@@ -512,8 +545,12 @@ void put_spell(std::string& out, const Target& t, const Path& p, bool whole_firs
   out.resize(at + head + p.size() - 1);
   char* o = &out[at];
   if (whole_first) {
-    uint64_t kmer = kmer_of(t, p[0]);
-    for (int i = t.k - 1; i >= 0; --i) { o[i] = LAST[kmer & 3]; kmer >>= 2; }
+    if (t.plain && !t.kmers && p[0] < t.n_ref) {
+      memcpy(o, t.seq + p[0], (size_t)t.k);
+    } else {
+      uint64_t kmer = kmer_of(t, p[0]);
+      for (int i = t.k - 1; i >= 0; --i) { o[i] = LAST[kmer & 3]; kmer >>= 2; }
+    }
   } else {
     o[0] = tail_of(t, p[0]);
   }
@@ -529,10 +566,64 @@ void put_spell(std::string& out, const Target& t, const Path& p, bool whole_firs
     size_t j = i + 1;                                       // a stretch of the target's own consecutive k-mers
     while (j < n && p[j] == p[j - 1] + 1 && p[j] < t.n_ref) ++j;
     const char* src = t.seq + node + t.k - 1;
-    for (size_t q = 0; q < j - i; ++q) o[q] = LAST[base_code(src[q])];
+    if (t.plain) memcpy(o, src, j - i);
+    else
+      for (size_t q = 0; q < j - i; ++q) o[q] = LAST[base_code(src[q])];
     o += j - i;
     i = j;
   }
+}
+
+// 0 ok, 1 IndexError, 2 "mutation identification could be incorrect", 3 assertion
+// (`known`: split_paths(ref, alt) when the caller has it already)
+int name_variant(Scratch& w, const Target& t, const Path& ref, const Path& alt, int64_t offset, std::string* out,
+                 const Split* known = nullptr) {
+  Split sp;
+  if (known) sp = *known;
+  else if (!split_paths(ref, alt, t.k, &sp)) return 1;
+  // ref[start:end_ref] and alt[start:end_var] as Python slices them
+  auto clamp = [](int64_t n, int64_t lo, int64_t hi, int64_t* a, int64_t* b) {
+    if (lo < 0) lo = std::max<int64_t>(0, lo + n);
+    if (hi < 0) hi = std::max<int64_t>(0, hi + n);
+    lo = std::min(lo, n);
+    hi = std::min(hi, n);
+    *a = lo;
+    *b = std::max(lo, hi);
+  };
+  int64_t r0, r1, a0, a1;
+  clamp((int64_t)ref.size(), sp.start, sp.end_ref, &r0, &r1);
+  clamp((int64_t)alt.size(), sp.start, sp.end_var, &a0, &a1);
+  if ((int64_t)ref.size() - (r1 - r0) + (a1 - a0) != (int64_t)alt.size()) return 2;
+  std::string &gone = w.gone, &neu = w.neu;
+  gone.resize((size_t)(r1 - r0));
+  for (int64_t i = r0; i < r1; ++i) gone[(size_t)(i - r0)] = tail_of(t, ref[(size_t)i]);
+  neu.resize((size_t)(a1 - a0));
+  for (int64_t i = a0; i < a1; ++i) neu[(size_t)(i - a0)] = tail_of(t, alt[(size_t)i]);
+  if (!gone.empty()) {
+    if (gone == neu) return 3;
+    // while gone[-(cut+1):] == neu[-(cut+1):]: cut += 1 — with gone != neu that is the length of the common suffix
+    // (once cut + 1 exceeds the shorter string the two slices differ in length)
+    size_t cut = 0;
+    const size_t lim = std::min(gone.size(), neu.size());
+    while (cut < lim && gone[gone.size() - 1 - cut] == neu[neu.size() - 1 - cut]) ++cut;
+    if (cut) {
+      gone.resize(cut >= gone.size() ? 0 : gone.size() - cut);
+      neu.resize(cut >= neu.size() ? 0 : neu.size() - cut);
+    }
+  }
+  const char* kind;
+  if (sp.end_ref == sp.end_var) kind = sp.start == sp.end_ref ? "Reference" : "Substitution";
+  else if (sp.start == sp.end_ovl) kind = "ITD";
+  else if (sp.end_ref < sp.end_var) kind = gone.empty() ? "Insertion" : "Indel";
+  else kind = neu.empty() ? "Deletion" : "Indel";
+  if (!strcmp(kind, "Reference")) { *out = "Reference\t"; return 0; }
+  for (char& c : gone) c = (char)tolower((unsigned char)c);
+  out->clear();
+  *out += kind; *out += '\t';
+  put_int(*out, (long long)(sp.start + t.k + offset)); *out += ':';
+  *out += gone; *out += '/'; *out += neu; *out += ':';
+  put_int(*out, (long long)(sp.end_ref + 1 + offset));
+  return 0;
 }
 
 // One TSV row (no newline) appended to `out`; `seq` is either given or spelled from `seq_path`.
@@ -610,17 +701,13 @@ bool row_less(const RowRec& a, const RowRec& b) {
   return na < nb;
 }
 
-bool is_reference(const Path& p, int64_t n_ref) {
-  if ((int64_t)p.size() != n_ref) return false;
-  for (int64_t i = 0; i < n_ref; ++i) if (p[(size_t)i] != i) return false;
-  return true;
-}
-
 // km_amd/report.py: cluster_groups
-struct Group { int64_t lo, hi; std::vector<int> members; };
-void cluster_groups(const std::vector<Split>& diffs, std::vector<Group>* out) {
-  std::vector<int> todo(diffs.size());
+// (the groups land in w.groups[0 .. w.n_groups): the vectors keep their capacity from target to target)
+void cluster_groups(const std::vector<Split>& diffs, Scratch& w) {
+  std::vector<int>& todo = w.todo;
+  todo.resize(diffs.size());
   for (size_t i = 0; i < diffs.size(); ++i) todo[i] = (int)i;
+  w.n_groups = 0;
   auto first_overlap = [&](int64_t lo, int64_t hi) -> int {
     for (int v : todo) {
       const int64_t s = diffs[(size_t)v].start, e = diffs[(size_t)v].end_ref;
@@ -634,7 +721,12 @@ void cluster_groups(const std::vector<Split>& diffs, std::vector<Group>* out) {
   while (!todo.empty()) {
     const int seed = todo.front();
     todo.erase(todo.begin());
-    Group g{diffs[(size_t)seed].start, diffs[(size_t)seed].end_ref, {seed}};
+    if (w.n_groups == w.groups.size()) w.groups.emplace_back();
+    Group& g = w.groups[w.n_groups++];
+    g.lo = diffs[(size_t)seed].start;
+    g.hi = diffs[(size_t)seed].end_ref;
+    g.members.clear();
+    g.members.push_back(seed);
     int v = first_overlap(g.lo, g.hi);
     while (v != -1) {
       todo.erase(std::find(todo.begin(), todo.end(), v));
@@ -643,7 +735,6 @@ void cluster_groups(const std::vector<Split>& diffs, std::vector<Group>* out) {
       g.hi = std::max(g.hi, diffs[(size_t)v].end_ref);
       v = first_overlap(g.lo, g.hi);
     }
-    out->push_back(g);
   }
 }
 
@@ -667,23 +758,32 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
     // lean delivery of a bare-reference target: its single row needs the path's min coverage and
     // whether every count is 0 (then PathQuant's rVAF aliases coef and both print nan)
     const double expr0 = t.ref_max == 0 ? nan : -1.0;
-    if (t.n_paths != 1 || !is_reference(t.paths[0], n_ref)) return 3;
+    if (t.n_paths != 1 || !t.is_ref[0]) return 3;
     put_row(out, db, t.name, REFERENCE, nan, expr0, t.min_cov[0], 0, t, nullptr, t.seq, ref_len, expr0, t.seq, ref_len, "vs_ref");
     out.push_back('\n');
     return 0;
   }
   uint32_t ref_max = 0;
   {
-    // the reference fits float32 counts (PathQuant.py:99): running sums of exactly those values
+    // the reference fits float32 counts (PathQuant.py:99): running sums of exactly those values — the counts
+    // themselves below 2^24 (every count of a real database), the nearest float32 above
     w.prefix.resize((size_t)t.n_nodes + 1);
-    uint64_t acc = 0;
     uint64_t* pre = w.prefix.data();
+    const uint32_t* cnt = t.counts;
+    uint32_t all_max = 0;
+    for (int64_t i = 0; i < n_ref; ++i) ref_max = std::max(ref_max, cnt[i]);
+    for (int64_t i = n_ref; i < t.n_nodes; ++i) all_max = std::max(all_max, cnt[i]);
+    all_max = std::max(all_max, ref_max);
+    uint64_t acc = 0;
     pre[0] = 0;
-    for (int64_t i = 0; i < t.n_nodes; ++i) {
-      const uint32_t c = t.counts[i];
-      if (i < n_ref) ref_max = std::max(ref_max, c);
-      acc += c < (1u << 24) ? (uint64_t)c : (uint64_t)(float)c;
-      pre[i + 1] = acc;
+    if (all_max < (1u << 24)) {
+      for (int64_t i = 0; i < t.n_nodes; ++i) { acc += cnt[i]; pre[i + 1] = acc; }
+    } else {
+      for (int64_t i = 0; i < t.n_nodes; ++i) {
+        const uint32_t c = cnt[i];
+        acc += c < (1u << 24) ? (uint64_t)c : (uint64_t)(float)c;
+        pre[i + 1] = acc;
+      }
     }
   }
   Path& ref = w.ref;                                     // 0 .. n_ref-1: what is there from the last target stays
@@ -691,9 +791,11 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
     const size_t have = ref.size();
     ref.resize((size_t)n_ref);
     for (size_t i = have; i < (size_t)n_ref; ++i) ref[i] = (int64_t)i;
+    w.ref_run.clear();
+    if (n_ref > 0) { w.ref_run.push_back(0); w.ref_run.push_back(n_ref); }
   }
   const double ref_expr = ref_max == 0 ? nan : -1.0;
-  if (t.n_paths == 1 && is_reference(t.paths[0], n_ref)) {
+  if (t.n_paths == 1 && t.is_ref[0]) {
     put_row(out, db, t.name, REFERENCE, nan, ref_expr, t.min_cov[0], 0, t, nullptr, t.seq, ref_len, ref_expr, t.seq, ref_len, "vs_ref");
     out.push_back('\n');
     return 0;
@@ -702,22 +804,26 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
   auto fail = [&](int rc) { out.resize(out0); return rc; };
   auto close_row = [&](RowRec& r, const std::string& name, long long mc, const char* note) {
     r.len = out.size() - r.off;
+    out.push_back('\n');                                  // every row is terminated: blocks concatenate into the TSV
     r.name = name;
     r.mincov.clear(); put_int(r.mincov, mc);
     r.note = note;
   };
-  std::string name;
+  std::string& name = w.name;
+  w.diffs.resize(t.n_paths);
   for (size_t pi = 0; pi < t.n_paths; ++pi) {
     const Path& p = t.paths[pi];
-    if (is_reference(p, n_ref)) {
+    if (t.is_ref[pi]) {
       RowRec& r = new_row(w, out);
       put_row(out, db, t.name, REFERENCE, nan, ref_expr, t.min_cov[pi], 0, t, nullptr, t.seq, ref_len, ref_expr, t.seq, ref_len, "vs_ref");
       close_row(r, REFERENCE, t.min_cov[pi], "vs_ref");
       continue;
     }
     w.set.clear(); w.set.push_back(&p); w.set.push_back(&ref);
+    w.set_runs.clear(); w.set_runs.push_back(&w.path_runs[pi]); w.set_runs.push_back(&w.ref_run);
     fit_paths(w, w.set, n_total, t.counts);
-    const int rc = name_variant(t, ref, p, 0, &name);
+    if (!split_paths(ref, p, k, &w.diffs[pi])) return fail(1);       // (kept for the clusters below)
+    const int rc = name_variant(w, t, ref, p, 0, &name, &w.diffs[pi]);
     if (rc) return fail(rc);
     RowRec& r = new_row(w, out);
     put_row(out, db, t.name, name, w.rvaf[0], w.coef[0], t.min_cov[pi], 0, t, &p, nullptr, 0, w.coef[1], t.seq, ref_len, "vs_ref");
@@ -725,14 +831,13 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
   }
   if (t.n_paths) {
     std::vector<Split>& diffs = w.diffs;
-    diffs.resize(t.n_paths);
-    for (size_t pi = 0; pi < t.n_paths; ++pi)
-      if (!split_paths(ref, t.paths[pi], k, &diffs[pi])) return fail(1);
-    std::vector<Group> groups;
-    cluster_groups(diffs, &groups);
+    for (size_t pi = 0; pi < t.n_paths; ++pi)              // the reference against itself: nothing differs
+      if (t.is_ref[pi]) diffs[pi] = Split{n_ref, n_ref, n_ref, n_ref};
+    cluster_groups(diffs, w);
     int num = 0;
-    for (const Group& g : groups) {
-      if (g.members.size() == 1 && is_reference(t.paths[(size_t)g.members[0]], n_ref)) continue;
+    for (size_t gi = 0; gi < w.n_groups; ++gi) {
+      const Group& g = w.groups[gi];
+      if (g.members.size() == 1 && t.is_ref[(size_t)g.members[0]]) continue;
       ++num;
       int64_t size = 0;
       for (int v : g.members)
@@ -749,10 +854,14 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
       w.set.clear();
       w.set.push_back(&cref);
       for (size_t q = 0; q < n_clip; ++q) w.set.push_back(&w.clipped[q]);
+      w.cref_run.clear();                                  // a slice of 0 .. n_ref-1
+      if (!cref.empty()) { w.cref_run.push_back(cref.front()); w.cref_run.push_back(cref.back() + 1); }
+      w.set_runs.assign(w.set.size(), nullptr);
+      w.set_runs[0] = &w.cref_run;
       fit_paths(w, w.set, n_total, t.counts);
-      w.tmp.clear();
-      put_spell(w.tmp, t, cref, true);                     // the cluster's reference sequence
-      const std::string cref_seq = w.tmp;
+      std::string& cref_seq = w.cref_seq;                  // the cluster's reference sequence
+      cref_seq.clear();
+      put_spell(cref_seq, t, cref, true);
       char note[64];
       snprintf(note, sizeof note, "cluster %d n=%d", num, (int)n_clip);
       for (size_t q = 0; q < n_clip; ++q) {
@@ -760,7 +869,7 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
         if (p.empty()) return fail(4);                     // min() of an empty sequence
         uint32_t mc = 0xFFFFFFFFu;
         for (int64_t node : p) mc = std::min(mc, t.counts[node]);
-        const int rc = name_variant(t, cref, p, off, &name);
+        const int rc = name_variant(w, t, cref, p, off, &name);
         if (rc) return fail(rc);
         RowRec& r = new_row(w, out);
         put_row(out, db, t.name, name, w.rvaf[q + 1], w.coef[q + 1], mc, off, t, &p, nullptr, 0, w.coef[0],
@@ -773,12 +882,14 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
   const size_t nr = w.n_rows;
   w.order.resize(nr);
   for (size_t i = 0; i < nr; ++i) w.order[i] = i;
-  std::stable_sort(w.order.begin(), w.order.end(), [&](size_t a, size_t b) { return row_less(w.rows[a], w.rows[b]); });
+  if (nr > 1) std::stable_sort(w.order.begin(), w.order.end(), [&](size_t a, size_t b) { return row_less(w.rows[a], w.rows[b]); });
+  bool in_place = true;
+  for (size_t i = 0; i < nr; ++i) in_place = in_place && w.order[i] == i;
+  if (in_place) return 0;                                 // they were made in that order
   w.tmp.clear();
   for (size_t i = 0; i < nr; ++i) {
     const RowRec& r = w.rows[w.order[i]];
-    w.tmp.append(out, r.off, r.len);
-    w.tmp.push_back('\n');                                // every row is terminated: blocks concatenate into the TSV
+    w.tmp.append(out, r.off, r.len + 1);
   }
   out.resize(out0);
   out += w.tmp;
@@ -975,6 +1086,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
             row_off[ti + 1] = 0;
             if (r.status[ti] != KM_T_OK) continue;
             Target t;
+            t.plain = false;
             t.name = in->names[ti] ? in->names[ti] : "";
             t.seq = (const char*)in->bases + in->base_off[ti];
             t.seq_len = (size_t)(in->base_off[ti + 1] - in->base_off[ti]);
@@ -1033,21 +1145,44 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
             t.n_paths = n_paths;
             w.min_cov.assign(r.path_min_cov + p0, r.path_min_cov + p1);
             t.min_cov = w.min_cov.data();
+            w.is_ref.resize(n_paths);
+            t.is_ref = w.is_ref.data();
+            if (w.path_runs.size() < n_paths) w.path_runs.resize(n_paths);
             bool consistent = true;
             for (uint32_t p = p0; p < p1 && consistent; ++p) {
               Path& path = w.paths[p - p0];
               path.clear();
+              std::vector<int64_t>& runs = w.path_runs[p - p0];
+              runs.clear();
               if (r.run_off[p + 1] < r.run_off[p]) { consistent = false; break; }
+              bool chain = true;                           // every run starts where the one before it ended, from 0
               for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
                 // every node of a path is one of this target's nodes (fit_paths indexes by it)
                 if ((int64_t)r.run_start[q] + (int64_t)r.run_len[q] > t.n_nodes) { consistent = false; break; }
                 const size_t at = path.size();
+                chain = chain && (size_t)r.run_start[q] == at;
                 path.resize(at + r.run_len[q]);
-                for (uint32_t j = 0; j < r.run_len[q]; ++j) path[at + j] = (int64_t)r.run_start[q] + j;
+                int64_t* dst = path.data() + at;
+                const int64_t first = (int64_t)r.run_start[q];
+                const uint32_t len = r.run_len[q];
+                runs.push_back(first); runs.push_back(first + len);
+                for (uint32_t j = 0; j < len; ++j) dst[j] = first + j;
               }
+              w.is_ref[p - p0] = chain && (int64_t)path.size() == t.n_ref;     // the path 0, 1, .. n_ref-1
             }
             if (!consistent) { err[ti] = 5; continue; }
-            if (lean && !(n_paths == 1 && is_reference(t.paths[0], t.n_ref))) { err[ti] = 5; continue; }
+            if (lean && !(n_paths == 1 && w.is_ref[0])) { err[ti] = 5; continue; }
+            {
+              // (the scan the per-base spelling would otherwise repeat for every row of the target)
+              const size_t len = (size_t)(t.n_ref + t.k - 1);
+              const uint8_t* sq = (const uint8_t*)t.seq;
+              uint8_t other = 0;
+              for (size_t i = 0; i < len; ++i) {
+                const uint8_t c = sq[i];
+                other |= (uint8_t)((c != 'A') & (c != 'C') & (c != 'G') & (c != 'T'));
+              }
+              t.plain = other == 0;
+            }
             g_tie = false;
             g_fit_iters = 0;
             const auto tt0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
