@@ -85,18 +85,44 @@ inline bool wrap_index(int64_t i, int64_t n, int64_t* out) {
 }
 
 // km_amd/report.py: split_paths.  Returns false where Python raises IndexError.
-bool split_paths(const Path& ref, const Path& alt, int k, Split* s) {
+// (`alt_runs`: the stretches of consecutive nodes of `alt` as (first, last + 1) pairs, usable when `ref` is the
+// path 0, 1, .. nr-1 — then where the two part and where they meet again is read off the stretches, not the nodes.)
+bool split_paths(const Path& ref, const Path& alt, int k, Split* s, const std::vector<int64_t>* alt_runs = nullptr) {
   const int64_t nr = (int64_t)ref.size(), na = (int64_t)alt.size();
   const int64_t m = std::min(nr, na);
   int64_t start = m;
-  for (int64_t i = 0; i < m; ++i)
-    if (ref[i] != alt[i]) { start = i; break; }
+  if (alt_runs) {
+    // alt[i] == i holds for a whole stretch or for none of it
+    int64_t at = 0;
+    for (size_t q = 0; q + 1 < alt_runs->size() && at < m; q += 2) {
+      const int64_t a = (*alt_runs)[q], b = (*alt_runs)[q + 1];
+      if (b <= a) continue;
+      if (a != at) { start = at; break; }
+      at += b - a;
+    }
+  } else {
+    for (int64_t i = 0; i < m; ++i)
+      if (ref[i] != alt[i]) { start = i; break; }
+  }
   const int64_t room = m - (start + k) + 1;
   int64_t same = 0;
   if (room > 0) {
     same = room;
-    for (int64_t i = 0; i < room; ++i)
-      if (ref[nr - 1 - i] != alt[na - 1 - i]) { same = i; break; }
+    if (alt_runs) {
+      // alt[j] == j + (nr - na), counted from the end: again a whole stretch or none of it
+      int64_t end = na, got = 0;
+      for (size_t q = alt_runs->size(); q >= 2 && got < room; q -= 2) {
+        const int64_t a = (*alt_runs)[q - 2], b = (*alt_runs)[q - 1];
+        if (b <= a) continue;
+        if (b - end != nr - na) break;
+        got += b - a;
+        end -= b - a;
+      }
+      same = std::min(got, room);
+    } else {
+      for (int64_t i = 0; i < room; ++i)
+        if (ref[nr - 1 - i] != alt[na - 1 - i]) { same = i; break; }
+    }
   }
   const int64_t end_ref = nr - same, end_var = na - same;
   const int64_t room2 = end_ref - start;
@@ -538,7 +564,9 @@ inline void put_int(std::string& out, long long v) {
 }
 
 // the sequence a path spells, appended to `out`
-void put_spell(std::string& out, const Target& t, const Path& p, bool whole_first) {
+// (`runs`: the path's stretches of consecutive nodes as (first, last + 1) pairs, when the caller has them)
+void put_spell(std::string& out, const Target& t, const Path& p, bool whole_first,
+               const std::vector<int64_t>* runs = nullptr) {
   if (p.empty()) return;
   const size_t at = out.size();
   const size_t head = whole_first ? (size_t)t.k : 1;
@@ -560,16 +588,33 @@ void put_spell(std::string& out, const Target& t, const Path& p, bool whole_firs
     for (size_t i = 1; i < n; ++i) *o++ = LAST[t.kmers[p[i]] & 3];
     return;
   }
+  auto own = [&](int64_t lo, int64_t hi) {                   // the last bases of the target's own k-mers lo .. hi-1
+    const char* src = t.seq + lo + t.k - 1;
+    const size_t len = (size_t)(hi - lo);
+    if (t.plain) memcpy(o, src, len);
+    else
+      for (size_t q = 0; q < len; ++q) o[q] = LAST[base_code(src[q])];
+    o += len;
+  };
+  if (runs) {
+    bool head_done = false;                                 // p[0] is spelled already
+    for (size_t q = 0; q + 1 < runs->size(); q += 2) {
+      int64_t lo = (*runs)[q];
+      const int64_t hi = (*runs)[q + 1];
+      if (hi <= lo) continue;
+      if (!head_done) { ++lo; head_done = true; }
+      const int64_t mid = std::min(hi, std::max(lo, t.n_ref));
+      if (lo < mid) own(lo, mid);
+      for (int64_t node = mid; node < hi; ++node) *o++ = LAST[t.extra[node - t.n_ref] & 3];
+    }
+    return;
+  }
   for (size_t i = 1; i < n;) {
     const int64_t node = p[i];
     if (node >= t.n_ref) { *o++ = LAST[t.extra[node - t.n_ref] & 3]; ++i; continue; }
     size_t j = i + 1;                                       // a stretch of the target's own consecutive k-mers
     while (j < n && p[j] == p[j - 1] + 1 && p[j] < t.n_ref) ++j;
-    const char* src = t.seq + node + t.k - 1;
-    if (t.plain) memcpy(o, src, j - i);
-    else
-      for (size_t q = 0; q < j - i; ++q) o[q] = LAST[base_code(src[q])];
-    o += j - i;
+    own(node, node + (int64_t)(j - i));
     i = j;
   }
 }
@@ -629,11 +674,12 @@ int name_variant(Scratch& w, const Target& t, const Path& ref, const Path& alt, 
 // One TSV row (no newline) appended to `out`; `seq` is either given or spelled from `seq_path`.
 void put_row(std::string& out, const char* db, const char* query, const std::string& name, double rvaf, double expr,
              long long min_cov, long long off, const Target& t, const Path* seq_path, const char* seq, size_t seq_len,
-             double ref_expr, const char* ref_seq, size_t ref_len, const char* note) {
+             double ref_expr, const char* ref_seq, size_t ref_len, const char* note,
+             const std::vector<int64_t>* seq_runs = nullptr) {
   out += db; out += '\t'; out += query; out += '\t'; out += name; out += '\t';
   put_float(out, "%.3f", rvaf); out += '\t'; put_float(out, "%.1f", expr); out += '\t';
   put_int(out, min_cov); out += '\t'; put_int(out, off); out += '\t';
-  if (seq_path) put_spell(out, t, *seq_path, true);
+  if (seq_path) put_spell(out, t, *seq_path, true, seq_runs);
   else out.append(seq, seq_len);
   out += '\t'; put_float(out, "%.1f", ref_expr); out += '\t'; out.append(ref_seq, ref_len); out += '\t'; out += note;
 }
@@ -822,11 +868,12 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
     w.set.clear(); w.set.push_back(&p); w.set.push_back(&ref);
     w.set_runs.clear(); w.set_runs.push_back(&w.path_runs[pi]); w.set_runs.push_back(&w.ref_run);
     fit_paths(w, w.set, n_total, t.counts);
-    if (!split_paths(ref, p, k, &w.diffs[pi])) return fail(1);       // (kept for the clusters below)
+    if (!split_paths(ref, p, k, &w.diffs[pi], &w.path_runs[pi])) return fail(1);   // (kept for the clusters below)
     const int rc = name_variant(w, t, ref, p, 0, &name, &w.diffs[pi]);
     if (rc) return fail(rc);
     RowRec& r = new_row(w, out);
-    put_row(out, db, t.name, name, w.rvaf[0], w.coef[0], t.min_cov[pi], 0, t, &p, nullptr, 0, w.coef[1], t.seq, ref_len, "vs_ref");
+    put_row(out, db, t.name, name, w.rvaf[0], w.coef[0], t.min_cov[pi], 0, t, &p, nullptr, 0, w.coef[1], t.seq, ref_len, "vs_ref",
+            &w.path_runs[pi]);
     close_row(r, name, t.min_cov[pi], "vs_ref");
   }
   if (t.n_paths) {
