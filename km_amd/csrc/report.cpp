@@ -14,6 +14,8 @@
 // The least-squares start is the minimum-norm solution through a one-sided Jacobi SVD with
 // numpy's rcond=None cut-off; it agrees with LAPACK's gelsd to ~1e-13 relative, far inside the
 // printed %.3f / %.1f — except on rounding ties and near-singular fits, which are flagged.
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1001,7 +1003,28 @@ struct Team {
   unsigned n_active = 0, pending = 0;
   unsigned long long generation = 0;
   bool quit = false;
-  void loop(unsigned me) {
+  // A new worker starts on the CPU of the thread that made it, and a thread that only ever runs for a fraction of
+  // a millisecond at a time is not worth moving to the scheduler's periodic balancing: measured, a whole team sat
+  // on ONE CPU for hundreds of calls (every call then took the single-thread time), in about half of all process
+  // starts.  So each worker moves itself once, when it starts, to its own CPU of those the process may use
+  // (counted on from the CPU of its maker), and then takes the full mask back: a first placement, not a pin.
+  // KM_REPORT_SPREAD=0 leaves it to the scheduler.
+  static void spread(unsigned me, int maker_cpu) {
+    if (const char* e = getenv("KM_REPORT_SPREAD")) if (atoi(e) == 0) return;
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    if (sched_getaffinity(0, sizeof all, &all) != 0) return;
+    int allowed[CPU_SETSIZE], n = 0, at = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &all)) { if (c == maker_cpu) at = n; allowed[n++] = c; }
+    if (n < 2) return;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(allowed[(at + (int)me) % n], &one);
+    if (sched_setaffinity(0, sizeof one, &one) == 0) sched_setaffinity(0, sizeof all, &all);
+  }
+  void loop(unsigned me, int maker_cpu) {
+    spread(me, maker_cpu);
     unsigned long long seen = 0;
     for (;;) {
       std::function<void(unsigned)> f;
@@ -1023,7 +1046,7 @@ struct Team {
   void run(unsigned n, const std::function<void(unsigned)>& f) {
     {
       std::lock_guard<std::mutex> lk(mu);
-      while (threads.size() + 1 < n) { const unsigned me = (unsigned)threads.size() + 1; threads.emplace_back([this, me] { loop(me); }); }
+      while (threads.size() + 1 < n) { const unsigned me = (unsigned)threads.size() + 1; const int cpu = sched_getcpu(); threads.emplace_back([this, me, cpu] { loop(me, cpu); }); }
       job = f;
       n_active = n;
       pending = n - 1;
@@ -1198,22 +1221,27 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
             bool consistent = true;
             for (uint32_t p = p0; p < p1 && consistent; ++p) {
               Path& path = w.paths[p - p0];
-              path.clear();
               std::vector<int64_t>& runs = w.path_runs[p - p0];
               runs.clear();
               if (r.run_off[p + 1] < r.run_off[p]) { consistent = false; break; }
-              bool chain = true;                           // every run starts where the one before it ended, from 0
+              size_t total = 0;
               for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
                 // every node of a path is one of this target's nodes (fit_paths indexes by it)
                 if ((int64_t)r.run_start[q] + (int64_t)r.run_len[q] > t.n_nodes) { consistent = false; break; }
-                const size_t at = path.size();
+                total += r.run_len[q];
+              }
+              if (!consistent) break;
+              path.resize(total);                          // (what the last target left in it is overwritten, not cleared)
+              bool chain = true;                           // every run starts where the one before it ended, from 0
+              size_t at = 0;
+              for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
                 chain = chain && (size_t)r.run_start[q] == at;
-                path.resize(at + r.run_len[q]);
                 int64_t* dst = path.data() + at;
                 const int64_t first = (int64_t)r.run_start[q];
                 const uint32_t len = r.run_len[q];
                 runs.push_back(first); runs.push_back(first + len);
                 for (uint32_t j = 0; j < len; ++j) dst[j] = first + j;
+                at += len;
               }
               w.is_ref[p - p0] = chain && (int64_t)path.size() == t.n_ref;     // the path 0, 1, .. n_ref-1
             }
