@@ -314,7 +314,10 @@ typedef struct {
  * 100 = rows delivered, but a printed rVAF / expression sits
  * within 1e-6 of a %.3f / %.1f rounding tie, where the last bits of the least-squares solver
  * decide the digit: a caller that needs the reference's exact text recomputes that target with
- * numpy (km_amd.lib.report_rows does).  Release the three arrays with km_report_free. */
+ * numpy (km_amd.lib.report_rows does).  Release the three arrays with km_report_free.
+ * Threads: a team of KM_REPORT_THREADS workers (default min(cores, 16)) kept between calls; each worker places
+ * itself on its own CPU once, when it is started, and keeps the process's affinity mask (KM_REPORT_SPREAD=0:
+ * placement is left to the scheduler). */
 int km_report_rows(const km_report_in_t* in, char** text, uint64_t** row_off, int32_t** err);
 void km_report_free(char* text, uint64_t* row_off, int32_t* err);
 
