@@ -378,3 +378,27 @@ def test_natural_order_of_rows_is_pythons(tmp_path):
         ka, kb = natural(a), natural(b)
         want = -1 if ka < kb else (1 if ka > kb else 0)
         assert g == want, (a, b, g, want)
+
+
+def test_worker_threads_spread_once_and_keep_the_process_mask(monkeypatch):
+    """The team of km_report_rows places each worker on a CPU of its own when the worker starts and then gives
+    it the process's mask back (csrc/report.cpp, Team::spread): afterwards no thread of the process is pinned,
+    the calling thread's mask is untouched, and the rows are those of a single-threaded call."""
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs Linux and two CPUs")
+    raw, seqs, results = _synthetic_view(n_targets=256)      # >= 64 targets per thread, or the call stays single-threaded
+    names = [r["name"] for r in results]
+    before = os.sched_getaffinity(0)
+    monkeypatch.setenv("KM_REPORT_THREADS", "1")
+    want = kmlib.report_rows(raw, names, seqs, 21, "view.jf")
+    monkeypatch.setenv("KM_REPORT_THREADS", "4")
+    for _ in range(3):
+        assert kmlib.report_rows(raw, names, seqs, 21, "view.jf") == want
+    assert os.sched_getaffinity(0) == before
+    masks = set()
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            masks.add(frozenset(os.sched_getaffinity(int(tid))))
+        except OSError:
+            pass                                             # a thread that ended meanwhile
+    assert masks == {frozenset(before)}
