@@ -11,9 +11,13 @@
 //   cluster_groups              <- km/utils/MutationFinder.py:651-723
 //   target rows + their order   <- km/utils/MutationFinder.py:575-648, 726-833,
 //                                  km/utils/PathQuant.py:37-49
-// The least-squares start is the minimum-norm solution through a one-sided Jacobi SVD with
-// numpy's rcond=None cut-off; it agrees with LAPACK's gelsd to ~1e-13 relative, far inside the
-// printed %.3f / %.1f — except on rounding ties and near-singular fits, which are flagged.
+// The least-squares start is the minimum-norm solution with numpy's rcond=None cut-off: from the eigenvectors
+// of the small matrix A^T A while the paths are well separated, through a one-sided Jacobi SVD of A itself for a
+// near-singular fit; it agrees with LAPACK's gelsd to ~1e-13 relative, far inside the printed %.3f / %.1f —
+// except on rounding ties and near-singular fits, which are flagged.
+// Paths arrive as runs of consecutive nodes and are worked on as such wherever the reference's arithmetic allows
+// it (which path is the reference, where a variant leaves and rejoins it, the patterns of a fit, the spelling);
+// the node vectors remain for the slices of a cluster.
 #include <sched.h>
 
 #include <algorithm>
