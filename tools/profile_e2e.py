@@ -35,6 +35,11 @@ print("write_rows %.1f ms for %d targets, %d rows (%.0f targets/s)"
       % (dt * 1e3, n, sink.getvalue().count("\n"), n / dt))
 pr = cProfile.Profile()
 pr.enable()
+finder.write_rows(tg, io.StringIO())
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pr = cProfile.Profile()
+pr.enable()
 finder.rows(tg)
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(12)
