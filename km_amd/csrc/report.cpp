@@ -44,7 +44,8 @@ namespace {
 thread_local bool g_tie = false;
 thread_local long g_fit_iters = 0;
 
-typedef std::vector<int64_t> Path;
+typedef int32_t Node;                // a node index of one target (targets are far below 2^31 nodes)
+typedef std::vector<Node> Path;
 
 struct Target {
   const char* name;
@@ -234,7 +235,8 @@ struct Scratch {
   std::vector<uint32_t> min_cov;
   std::vector<uint8_t> is_ref;         // per path of the target
   std::vector<uint32_t> counts32;      // a target's counts when the view carries them as 16-bit values
-  std::vector<uint64_t> prefix;        // prefix[i] = sum of the float32 values of the counts of nodes < i
+  const uint32_t* cnt = nullptr;       // the target's counts, and whether one of them is 2^24 or more (then a count
+  bool cnt_wide = false;               // enters a fit as its nearest float32, PathQuant.py:99)
   Path ref, cref;
   struct Event { int64_t pos; int32_t c, d; };
   std::vector<Event> events;
@@ -255,7 +257,7 @@ struct Scratch {
   std::vector<Split> diffs;
 };
 
-// km_amd/report.py: fit_paths over the node counts as float32 values (w.prefix holds their running sums) followed
+// km_amd/report.py: fit_paths over the node counts as float32 values (w.cnt: summed stretch by stretch) followed
 // by -1, -1 (the two capping nodes, on no path).  Leaves coef and rvaf in the scratch (rvaf == coef when every
 // coefficient is 0).
 //
@@ -284,7 +286,7 @@ size_t fit_patterns(Scratch& w, const std::vector<const Path*>& paths) {
     }
     const Path& p = *paths[c];
     const size_t n = p.size();
-    const int64_t* pd = p.data();
+    const Node* pd = p.data();
     size_t i = 0;
     while (i < n) {
       size_t j = i + 1;
@@ -310,7 +312,18 @@ size_t fit_patterns(Scratch& w, const std::vector<const Path*>& paths) {
   int32_t* pat = w.pat.data();
   int32_t* row = w.row.data();
   double *pat_sum = w.pat_sum.data(), *pat_n = w.pat_n.data();
-  const uint64_t* prefix = w.prefix.data();
+  // the sum of the float32 values of the counts of the nodes lo .. hi-1: integers, exact in any order
+  const uint32_t* cnt = w.cnt;
+  const bool wide = w.cnt_wide;
+  auto stretch_sum = [&](int64_t lo, int64_t hi) -> uint64_t {
+    uint64_t acc = 0;
+    if (!wide) {
+      for (int64_t i = lo; i < hi; ++i) acc += cnt[i];
+    } else {
+      for (int64_t i = lo; i < hi; ++i) { const uint32_t c = cnt[i]; acc += c < (1u << 24) ? (uint64_t)c : (uint64_t)(float)c; }
+    }
+    return acc;
+  };
   size_t n_pat = 0;
   int64_t active = 0, prev = 0;
   size_t last = 0;                                      // neighbours mostly share their pattern
@@ -331,7 +344,7 @@ size_t fit_patterns(Scratch& w, const std::vector<const Path*>& paths) {
         pat_sum[q] = 0.0; pat_n[q] = 0.0;
         ++n_pat;
       }
-      pat_sum[q] += (double)(prefix[(size_t)pos] - prefix[(size_t)prev]);
+      pat_sum[q] += (double)stretch_sum(prev, pos);
       pat_n[q] += (double)(pos - prev);
       last = q;
     }
@@ -817,32 +830,21 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
   }
   uint32_t ref_max = 0;
   {
-    // the reference fits float32 counts (PathQuant.py:99): running sums of exactly those values — the counts
+    // the reference fits float32 counts (PathQuant.py:99): the fits sum exactly those values — the counts
     // themselves below 2^24 (every count of a real database), the nearest float32 above
-    w.prefix.resize((size_t)t.n_nodes + 1);
-    uint64_t* pre = w.prefix.data();
     const uint32_t* cnt = t.counts;
     uint32_t all_max = 0;
     for (int64_t i = 0; i < n_ref; ++i) ref_max = std::max(ref_max, cnt[i]);
     for (int64_t i = n_ref; i < t.n_nodes; ++i) all_max = std::max(all_max, cnt[i]);
     all_max = std::max(all_max, ref_max);
-    uint64_t acc = 0;
-    pre[0] = 0;
-    if (all_max < (1u << 24)) {
-      for (int64_t i = 0; i < t.n_nodes; ++i) { acc += cnt[i]; pre[i + 1] = acc; }
-    } else {
-      for (int64_t i = 0; i < t.n_nodes; ++i) {
-        const uint32_t c = cnt[i];
-        acc += c < (1u << 24) ? (uint64_t)c : (uint64_t)(float)c;
-        pre[i + 1] = acc;
-      }
-    }
+    w.cnt = cnt;
+    w.cnt_wide = all_max >= (1u << 24);
   }
   Path& ref = w.ref;                                     // 0 .. n_ref-1: what is there from the last target stays
   {
     const size_t have = ref.size();
     ref.resize((size_t)n_ref);
-    for (size_t i = have; i < (size_t)n_ref; ++i) ref[i] = (int64_t)i;
+    for (size_t i = have; i < (size_t)n_ref; ++i) ref[i] = (Node)i;
     w.ref_run.clear();
     if (n_ref > 0) { w.ref_run.push_back(0); w.ref_run.push_back(n_ref); }
   }
@@ -902,7 +904,8 @@ int target_rows(Scratch& w, const Target& t, const char* db, std::string& out) {
       const size_t n_clip = g.members.size();
       for (size_t q = 0; q < n_clip; ++q) {
         const int v = g.members[q];
-        slice(t.paths[(size_t)v], off, diffs[(size_t)v].end_var + g.hi - diffs[(size_t)v].end_ref, &w.clipped[q]);
+        // (a path that IS the reference was not laid out: `ref` holds the same nodes)
+        slice(t.is_ref[(size_t)v] ? ref : t.paths[(size_t)v], off, diffs[(size_t)v].end_var + g.hi - diffs[(size_t)v].end_ref, &w.clipped[q]);
       }
       w.set.clear();
       w.set.push_back(&cref);
@@ -1235,19 +1238,26 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
                 total += r.run_len[q];
               }
               if (!consistent) break;
-              path.resize(total);                          // (what the last target left in it is overwritten, not cleared)
               bool chain = true;                           // every run starts where the one before it ended, from 0
               size_t at = 0;
               for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
                 chain = chain && (size_t)r.run_start[q] == at;
-                int64_t* dst = path.data() + at;
+                const int64_t first = (int64_t)r.run_start[q];
+                runs.push_back(first); runs.push_back(first + r.run_len[q]);
+                at += r.run_len[q];
+              }
+              const bool is_ref = chain && (int64_t)total == t.n_ref;                  // the path 0, 1, .. n_ref-1
+              w.is_ref[p - p0] = is_ref;
+              if (is_ref) { path.clear(); continue; }      // never read: target_rows has 0 .. n_ref-1 of its own
+              path.resize(total);                          // (what the last target left in it is overwritten, not cleared)
+              at = 0;
+              for (uint64_t q = r.run_off[p]; q < r.run_off[p + 1]; ++q) {
+                Node* dst = path.data() + at;
                 const int64_t first = (int64_t)r.run_start[q];
                 const uint32_t len = r.run_len[q];
-                runs.push_back(first); runs.push_back(first + len);
-                for (uint32_t j = 0; j < len; ++j) dst[j] = first + j;
+                for (uint32_t j = 0; j < len; ++j) dst[j] = (Node)(first + j);
                 at += len;
               }
-              w.is_ref[p - p0] = chain && (int64_t)path.size() == t.n_ref;     // the path 0, 1, .. n_ref-1
             }
             if (!consistent) { err[ti] = 5; continue; }
             if (lean && !(n_paths == 1 && w.is_ref[0])) { err[ti] = 5; continue; }
