@@ -1017,7 +1017,8 @@ struct Team {
   // (counted on from the CPU of its maker), and then takes the full mask back: a first placement, not a pin.
   // KM_REPORT_SPREAD=0 leaves it to the scheduler.
   static void spread(unsigned me, int maker_cpu) {
-    if (const char* e = getenv("KM_REPORT_SPREAD")) if (atoi(e) == 0) return;
+    int stride = 1;                                     // KM_REPORT_SPREAD=s: every s-th allowed CPU (0: leave it to the scheduler)
+    if (const char* e = getenv("KM_REPORT_SPREAD")) { stride = atoi(e); if (stride <= 0) return; }
     cpu_set_t all;
     CPU_ZERO(&all);
     if (sched_getaffinity(0, sizeof all, &all) != 0) return;
@@ -1027,7 +1028,7 @@ struct Team {
     if (n < 2) return;
     cpu_set_t one;
     CPU_ZERO(&one);
-    CPU_SET(allowed[(at + (int)me) % n], &one);
+    CPU_SET(allowed[(int)(((long)at + (long)me * stride) % n)], &one);
     if (sched_setaffinity(0, sizeof one, &one) == 0) sched_setaffinity(0, sizeof all, &all);
   }
   void loop(unsigned me, int maker_cpu) {

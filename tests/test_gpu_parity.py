@@ -1240,7 +1240,9 @@ def test_cli_two_ranks_target_sharded(tmp_path):
                        cwd=HERE, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = [l for l in p.stdout.splitlines()
-           if l.strip() and not l.startswith("#Elapsed time") and "peer ranks" not in l]   # gloo chatters on stdout
+           if l.strip() and not l.startswith("#Elapsed time") and "peer ranks" not in l
+           and (l.startswith("#") or "\t" in l)]     # gloo chatters on stdout, and two ranks' chatter can interleave
+                                                     # ("... is : " from one rank, "1" on a line of its own from the other)
     assert out == case["lines"]
     # sample-sharded driver, two ranks
     mat = _load("sample_matrix.json")
