@@ -1131,6 +1131,8 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
     constexpr uint32_t CHUNK = 32;
     const uint32_t n_chunks = (n + CHUNK - 1) / CHUNK;
     struct ChunkRec { uint32_t worker; size_t at; };
+    struct WorkerTrace { double first_us = 0, last_us = 0; uint32_t chunks = 0; int cpu = -1; char pad[40]; };
+    std::vector<WorkerTrace> wtrace;                      // KM_TRACE_HOST: when each worker started and ended, on which CPU
     std::vector<ChunkRec> chunk(n_chunks);
     unsigned n_thr = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     if (const char* e = getenv("KM_REPORT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (unsigned)v; }
@@ -1142,6 +1144,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
     if (on_team) { if (team().buf.size() < n_thr) team().buf.resize(n_thr); }
     else own_buf.resize(n_thr);
     std::vector<std::string>& wbuf = on_team ? team().buf : own_buf;
+    if (trace) wtrace.resize(n_thr);
     std::atomic<uint32_t> next(0), next_copy(0), arrived(0);
     std::atomic<bool> failed(false);
     std::atomic<int> phase(0);            // 1: offsets and the text buffer are ready, -1: allocation failed
@@ -1155,7 +1158,9 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
         std::string& out = wbuf[me];
         out.clear();
         out.reserve((size_t)n * 1600 / n_thr + 65536);
+        if (trace) { wtrace[me].first_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); wtrace[me].cpu = sched_getcpu(); }
         for (uint32_t c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) {
+          if (trace) ++wtrace[me].chunks;
           chunk[c] = ChunkRec{me, out.size()};
           for (uint32_t ti = c * CHUNK; ti < std::min<uint32_t>(n, (c + 1) * CHUNK); ++ti) {
             err[ti] = 0;
@@ -1289,6 +1294,7 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
       } catch (...) {
         failed = true;
       }
+      if (trace) wtrace[me].last_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count();
       // ---- every chunk is written: the last worker to arrive lays out the text
       if (arrived.fetch_add(1) + 1 == n_thr) {
         tr1 = std::chrono::steady_clock::now();
@@ -1326,6 +1332,11 @@ extern "C" int km_report_rows(const km_report_in_t* in, char** text_out, uint64_
               std::chrono::duration<double, std::milli>(tr1 - tr0).count(),
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count(),
               (unsigned long long)row_off[n]);
+    if (trace) {
+      fprintf(stderr, "[km host] report workers (cpu: first chunk at us .. last done at us, chunks):");
+      for (unsigned q = 0; q < n_thr; ++q) fprintf(stderr, " %d:%.0f..%.0f,%u", wtrace[q].cpu, wtrace[q].first_us, wtrace[q].last_us, wtrace[q].chunks);
+      fprintf(stderr, "\n");
+    }
     *text_out = text;
     *row_off_out = row_off;
     *err_out = err;
